@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Generate ``tests/golden/*`` by executing the REFERENCE classes in this container.
+
+Run from the repository root:  ``python oracle/gen_golden.py``  (needs ``/root/reference``).
+
+What runs the reference's own code: every ``forward`` / ``get_embedding`` / ``ArcMarginProduct``
+output below comes from classes defined in ``/root/reference/src/face_models.py`` (loaded by
+``oracle/ref_loader.py``; only the un-vendored ``torchvision.models.resnet18`` is a stub).
+``src/app.py`` cannot be imported here (streamlit / cv2 / facenet_pytorch / torchvision are absent),
+so the ``compare_faces`` known answers are produced by ``face_oracle.compare_faces``, a
+line-by-line restatement of `src/app.py:50-64` built on the same ``F.pairwise_distance``.
+
+Only numbers are written (npz / json): inputs are regenerated from seeds on both sides; weights are
+regenerated from seeds + the calibration pass (``oracle/weights.py``).  No reference source text is
+copied anywhere.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import frmap_amd.synth as synth  # noqa: E402
+from frmap_amd import gallery_io  # noqa: E402
+from oracle import face_oracle as fo  # noqa: E402
+from oracle import ref_loader, weights  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+NUM_CLASSES = 36
+
+
+def _np(t):
+    return t.detach().cpu().numpy().astype(np.float32)
+
+
+def gen_models(ref):
+    key_table = {}
+    for mt in ("baseline", "cnn", "arcface", "siamese", "hybrid"):
+        torch.manual_seed(0)
+        model = ref.get_model(mt, NUM_CLASSES)
+        shapes = {k: (tuple(v.shape), v.dtype) for k, v in model.state_dict().items()}
+        key_table[mt] = {k: [list(s), str(d).replace("torch.", "")] for k, (s, d) in shapes.items()}
+        sd = weights.calibrated_state_dict(mt, shapes, weights.SEEDS[mt][0])
+        missing = model.load_state_dict(sd, strict=True)
+        assert not missing.missing_keys and not missing.unexpected_keys
+        model.eval()
+        x = weights.golden_inputs(mt)
+        out = {}
+        with torch.no_grad():
+            if mt == "siamese":
+                e = model.get_embedding(x)
+                o1, o2 = model(x[:8], x[8:])
+                out["embedding"] = _np(e)
+                out["forward_out1"] = _np(o1)
+                out["forward_out2"] = _np(o2)
+                out["pair_dist"] = _np(F.pairwise_distance(o1, o2))
+            elif mt == "arcface":
+                labels = torch.arange(x.shape[0]) % NUM_CLASSES
+                out["embedding"] = _np(model.get_embedding(x))
+                out["forward"] = _np(model(x))                       # eval, no labels -> embedding
+                out["forward_labels"] = _np(model(x, labels))         # eval + labels -> val_classifier
+                out["labels"] = labels.numpy()
+                # pre-normalisation embedding (for relative-L2 checks), from the reference's own layers
+                f = model.features(x).view(x.size(0), -1)
+                out["pre_norm"] = _np(model.bn(model.embedding(f)))
+                out["embedding_b1"] = _np(model.get_embedding(x[:1]))
+            else:
+                out["forward"] = _np(model(x))
+                out["embedding"] = _np(model.get_embedding(x))
+                if mt == "cnn":
+                    out["embedding_b1"] = _np(model.get_embedding(x[:1]))   # .squeeze() -> (512,)
+        # the restatement must agree with the reference it restates, here and now
+        with torch.no_grad():
+            o_emb = fo.EMBEDDING[mt](sd, x)
+        err = (o_emb - torch.from_numpy(out["embedding"])).abs().max().item()
+        print(f"{mt:9s} oracle-vs-reference max|Δ| embedding = {err:.3e}")
+        assert err < 2e-5, (mt, err)
+        np.savez_compressed(os.path.join(GOLD, f"{mt}.npz"), **out)
+    with open(os.path.join(GOLD, "state_dict_keys.json"), "w") as f:
+        json.dump(key_table, f, indent=0, sort_keys=True)
+
+
+def gen_arcmargin(ref):
+    B, D, C = 32, 512, 1000
+    w = synth.randn(1003, (C, D), tag="arcmargin.weight")
+    x = synth.randn(2003, (B, D), tag="arcmargin.x")
+    lab = torch.from_numpy(np.random.Generator(np.random.PCG64(4003)).integers(0, C, B)).long()
+    out = {"labels": lab.numpy()}
+    for name, kw in (("s30_m05", dict(s=30.0, m=0.5)), ("s32_m05", dict(s=32.0, m=0.5)),
+                     ("s16_m03_easy", dict(s=16.0, m=0.3, easy_margin=True))):
+        head = ref.ArcMarginProduct(D, C, **kw)
+        with torch.no_grad():
+            head.weight.copy_(w)
+        head.eval()
+        with torch.no_grad():
+            y = head(x, lab)
+        out[name] = _np(y)
+        o = fo.arcmargin_eval(w, x, lab, **kw)
+        assert (o - y).abs().max().item() < 1e-5
+    np.savez_compressed(os.path.join(GOLD, "arcmargin.npz"), **out)
+
+
+def gen_gallery():
+    recs = gallery_io.read_gallery_file("/root/reference/face_references/face_references.pkl")
+    names = [r["name"] for r in recs]
+    emb = np.concatenate([r["embedding_numpy"] for r in recs], axis=0).astype(np.float32)
+    refs = [{"name": n, "embedding": torch.from_numpy(emb[i:i + 1])} for i, n in enumerate(names)]
+    G = len(refs)
+    dmat = np.zeros((G, G), np.float32)
+    for i in range(G):
+        for j in range(G):
+            dmat[i, j] = F.pairwise_distance(refs[i]["embedding"], refs[j]["embedding"]).item()
+    full = [list(fo.compare_faces(refs[i]["embedding"], refs, 1.0)) for i in range(G)]
+    loo = [list(fo.compare_faces(refs[i]["embedding"], refs[:i] + refs[i + 1:], 1.0)) for i in range(G)]
+    loo2 = [list(fo.compare_faces(refs[i]["embedding"], refs[:i] + refs[i + 1:], 2.0)) for i in range(G)]
+    doc = {"source": "face_references/face_references.pkl (read with the non-executing parser)",
+           "names": names, "image_paths": [r["image_path"] for r in recs],
+           "embeddings": [[float(v) for v in row] for row in emb],
+           "pairwise_distance": [[float(v) for v in row] for row in dmat],
+           "compare_full_thresh1": full, "compare_leave_one_out_thresh1": loo,
+           "compare_leave_one_out_thresh2": loo2}
+    with open(os.path.join(GOLD, "face_references.json"), "w") as f:
+        json.dump(doc, f)
+
+
+def gen_match():
+    out = {}
+    for G in (36, 1000):
+        gal = synth.unit_rows(3000 + G, G, 512)
+        probes_rand = synth.unit_rows(3500 + G, 16, 512, tag="probes")
+        # enrolment-style: probes are perturbed copies of gallery rows 0,5,10,...
+        src = torch.arange(16) * (G // 16)
+        noise = synth.randn(3600 + G, (16, 512), tag="noise")
+        probes_enrol = F.normalize(gal[src] + 0.02 * noise, dim=1)
+        for tag, probes in (("rand", probes_rand), ("enrol", probes_enrol)):
+            refs = [{"name": f"id{i}", "embedding": gal[i:i + 1]} for i in range(G)]
+            ids, dists, margins = [], [], []
+            for b in range(16):
+                name, d, idx = fo.compare_faces(probes[b:b + 1], refs, 1e9)
+                alld = torch.stack([F.pairwise_distance(probes[b:b + 1], r["embedding"])[0] for r in refs])
+                top2 = torch.topk(alld, 2, largest=False).values
+                ids.append(idx); dists.append(d); margins.append(float(top2[1] - top2[0]))
+            out[f"g{G}_{tag}_id"] = np.array(ids, np.int32)
+            out[f"g{G}_{tag}_dist"] = np.array(dists, np.float32)
+            out[f"g{G}_{tag}_margin"] = np.array(margins, np.float32)
+        out[f"g{G}_enrol_src"] = src.numpy().astype(np.int32)
+    np.savez_compressed(os.path.join(GOLD, "match.npz"), **out)
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(8)
+    ref = ref_loader.load_reference()
+    gen_gallery()
+    gen_match()
+    gen_arcmargin(ref)
+    gen_models(ref)
+    print("golden vectors written to", GOLD)
+
+
+if __name__ == "__main__":
+    main()
