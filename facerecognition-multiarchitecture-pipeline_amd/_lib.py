@@ -1,0 +1,80 @@
+"""ctypes binding of ``libfrmap_hip.so`` (C ABI declared in ``include/frmap_hip.h``).
+
+There is deliberately no fallback: if the shared library has not been built
+(``python -c "import __graft_entry__ as g; g.build()"`` or ``csrc/build.sh``) every compute entry
+point raises ``RuntimeError`` — the product path never routes through PyTorch eager or the CPU
+oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libfrmap_hip.so")
+ABI_VERSION = 1
+
+_lock = threading.Lock()
+_lib = None
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/frmap_hip.h one to one
+PROTOTYPES = {
+    "frmap_abi_version": (_i, []),
+    "frmap_last_error": (C.c_char_p, []),
+    "frmap_pack_input_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "frmap_pack_conv_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "frmap_small_cin_kpad": (_i, [_i, _i]),
+    "frmap_pack_conv_weight_c3": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "frmap_conv_small_cin": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "frmap_conv_igemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "frmap_maxpool": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "frmap_avgpool_global": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "frmap_avgpool_adaptive": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "frmap_linear_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "frmap_l2_normalize_f32": (_i, [_vp, _vp, _i, _i, _f, _vp]),
+    "frmap_cast_to_f32": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "frmap_cast_from_f32": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "frmap_head_workspace_bytes": (_sz, [_i, _i]),
+    "frmap_match_top1": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "frmap_cosine_logits": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "frmap_arcmargin_eval": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
+}
+
+
+def lib_available() -> bool:
+    return os.path.isfile(LIB_PATH)
+
+
+def load() -> C.CDLL:
+    """Load (once) and return the library; raise loudly if it is missing or has the wrong ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not lib_available():
+            raise RuntimeError(
+                f"HIP extension not built: {LIB_PATH} is missing. Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+                "There is no CPU / PyTorch fallback for this path.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if lib.frmap_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"libfrmap_hip.so ABI {lib.frmap_abi_version()} != expected {ABI_VERSION}; rebuild")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().frmap_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise RuntimeError(f"{what}: {msg} (rc={rc})")

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Build libfrmap_hip.so (gfx950) in-tree.  hipcc cross-compiles without a GPU.
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+OUT=../libfrmap_hip.so
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result"
+objs=()
+for f in conv_igemm.hip conv_small_cin.hip layout_pool.hip head_match.hip c_api.cpp; do
+  o="build_${f%.*}.o"
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ frmap_common.h -nt "$o" ] || [ ../../include/frmap_hip.h -nt "$o" ]; then
+    echo "hipcc $f"
+    if [[ "$f" == *.cpp ]]; then
+      $HIPCC $FLAGS -x hip -c "$f" -o "$o" &
+    else
+      $HIPCC $FLAGS -c "$f" -o "$o" &
+    fi
+  fi
+  objs+=("$o")
+done
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "${objs[@]}"
+echo "built $(realpath $OUT)"

@@ -1,0 +1,366 @@
+// fp32 heads and gallery matching on the exact-f32 matrix cores (v_mfma_f32_32x32x2_f32), gfx950.
+//
+//   frmap_linear_f32        nn.Linear (+ folded BatchNorm1d) (+ReLU)   face_models.py:32-33,75,467-468,488,678
+//   frmap_l2_normalize_f32  F.normalize(p=2, dim=1, eps)               face_models.py:179,525,590
+//   frmap_match_top1        compare_faces' arg-min over the gallery    app.py:58-63
+//   frmap_cosine_logits     class-centre cosine logits + arg-max       hyperparameter_tuning.py:1038-1046
+//   frmap_arcmargin_eval    ArcMarginProduct.forward, eval mode        face_models.py:351-429
+//
+// All four GEMM-shaped ops share one NT kernel  C[b][n] = sum_k A[b][k] * W[n][k]  (both operands
+// K-contiguous, like nn.Linear): 256 threads, tile 64 rows x 128 cols, K staged 32 at a time in LDS
+// (pitch 33 floats -> conflict-free column reads), wave w owns columns [32w, 32w+32) and both
+// 32-row halves.  fp32 in, fp32 accumulate: bitwise an fmaf chain, so arg-min / arg-max decisions
+// are taken on true fp32 scores.
+#include "frmap_common.h"
+
+enum { MODE_LINEAR = 0, MODE_COS = 1, MODE_ARC = 2, MODE_DIST = 3 };
+
+struct GemmEpi {
+  // LINEAR
+  const float* scale;
+  const float* shift;
+  int relu;
+  // COS / ARC
+  const float* inv_a;  // [B] 1/max(||a||,eps)
+  const float* inv_w;  // [N]
+  float s;
+  float m;
+  int easy;
+  const int64_t* label;
+  unsigned int* minmax_key;  // [2] ordered-uint keys (max, min) or null
+  unsigned long long* argkey;  // [B] packed (score, idx) keys or null
+  // DIST
+  const float* stat_a;  // [B][2] = (sum x^2, sum x)
+  const float* stat_w;  // [N][2]
+  float* out;           // [B][N] or null
+};
+
+__device__ __forceinline__ unsigned int f32_ordered(float f) {
+  const unsigned int b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b ^ 0x80000000u);
+}
+__device__ __forceinline__ float f32_unordered(unsigned int k) {
+  return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                          int B, int N, int K, GemmEpi ep) {
+  constexpr int BMr = 64, BNc = 128, KC = 32, PITCH = KC + 1;
+  __shared__ float As[BMr * PITCH];
+  __shared__ float Ws[BNc * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b0 = blockIdx.y * BMr, n0 = blockIdx.x * BNc;
+  const int li = lane & 31, lk = lane >> 5;
+
+  f32x16_t acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+  const int srow = tid >> 3, skq = (tid & 7) * 4;  // staging: 32 rows x 8 float4 per pass
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    float4 va[2], vw[4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int row = b0 + srow + r * 32;
+      va[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < B && k0 + skq < K) va[r] = *(const float4*)(A + (size_t)row * K + k0 + skq);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = n0 + srow + r * 32;
+      vw[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < N && k0 + skq < K) vw[r] = *(const float4*)(W + (size_t)row * K + k0 + skq);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      float* d = As + (srow + r * 32) * PITCH + skq;
+      d[0] = va[r].x; d[1] = va[r].y; d[2] = va[r].z; d[3] = va[r].w;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float* d = Ws + (srow + r * 32) * PITCH + skq;
+      d[0] = vw[r].x; d[1] = vw[r].y; d[2] = vw[r].z; d[3] = vw[r].w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < KC; kk += 2) {
+      const float a0 = As[li * PITCH + kk + lk];
+      const float a1 = As[(32 + li) * PITCH + kk + lk];
+      const float w = Ws[(wave * 32 + li) * PITCH + kk + lk];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, w, acc1, 0, 0, 0);
+    }
+  }
+
+  // epilogue: lane holds column n = n0 + 32*wave + (lane&31), rows (reg&3)+8*(reg>>2)+4*(lane>>5) (+32 for acc1)
+  const int n = n0 + wave * 32 + li;
+  const bool nvalid = n < N;
+  float cmax = -INFINITY, cmin = INFINITY;
+  float wscale = 1.f, wshift = 0.f, winv = 0.f, wn2 = 0.f, wsum = 0.f;
+  if (nvalid) {
+    if (MODE == MODE_LINEAR) {
+      wscale = ep.scale ? ep.scale[n] : 1.f;
+      wshift = ep.shift ? ep.shift[n] : 0.f;
+    } else if (MODE == MODE_DIST) {
+      wn2 = ep.stat_w[2 * n];
+      wsum = ep.stat_w[2 * n + 1];
+    } else {
+      winv = ep.inv_w[n];
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int b = b0 + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      const float dot = h ? acc1[r] : acc0[r];
+      const bool valid = nvalid && b < B;
+      if (MODE == MODE_LINEAR) {
+        if (valid) {
+          float v = dot * wscale + wshift;
+          if (ep.relu) v = fmaxf(v, 0.f);
+          ep.out[(size_t)b * N + n] = v;
+        }
+      } else if (MODE == MODE_COS) {
+        float v = -INFINITY;
+        if (valid) {
+          v = dot * ep.inv_a[b] * winv * ep.s;
+          if (ep.out) ep.out[(size_t)b * N + n] = v;
+        }
+        if (ep.argkey) {
+          // arg-max over n, first index wins ties: maximise (score, ~n)
+          unsigned long long key = valid ? (((unsigned long long)f32_ordered(v) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)n)) : 0ull;
+#pragma unroll
+          for (int o = 16; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(key, o, 64);
+            key = other > key ? other : key;
+          }
+          if (li == 0 && b < B && key) atomicMax(ep.argkey + b, key);
+        }
+      } else if (MODE == MODE_ARC) {
+        if (valid) {
+          const float cosr = dot * ep.inv_a[b] * winv;
+          cmax = fmaxf(cmax, cosr);
+          cmin = fminf(cmin, cosr);
+          const float lo = (float)(-1.0 + 1e-7), hi = (float)(1.0 - 1e-7);
+          const float c = fminf(fmaxf(cosr, lo), hi);
+          float v = c;
+          if (ep.label[b] == (int64_t)n) {
+            const float theta = acosf(c);
+            if (ep.easy) v = c > 0.f ? cosf(theta + ep.m) : c;
+            else v = cosf(fminf((float)(3.14159265358979323846 - 1e-4), theta + ep.m));
+          }
+          v *= ep.s;
+          if (isnan(v) || isinf(v)) v = 0.f;
+          ep.out[(size_t)b * N + n] = v;
+        }
+      } else {  // MODE_DIST: ||a - g + eps||^2 = |a|^2 + |g|^2 - 2 a.g + 2 eps (sum a - sum g) + K eps^2
+        unsigned long long key = ~0ull;
+        if (valid) {
+          const float eps = 1e-6f;
+          float d2 = ep.stat_a[2 * b] + wn2 - 2.f * dot + 2.f * eps * (ep.stat_a[2 * b + 1] - wsum) + (float)K * eps * eps;
+          d2 = fmaxf(d2, 0.f);
+          key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)n;
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+          const unsigned long long other = __shfl_xor(key, o, 64);
+          key = other < key ? other : key;
+        }
+        if (li == 0 && b < B && key != ~0ull) atomicMin(ep.argkey + b, key);
+      }
+    }
+  }
+  if (MODE == MODE_ARC && ep.minmax_key) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
+      cmin = fminf(cmin, __shfl_xor(cmin, o, 64));
+    }
+    if (lane == 0 && cmax >= cmin) {
+      atomicMax(ep.minmax_key, f32_ordered(cmax));
+      atomicMin(ep.minmax_key + 1, f32_ordered(cmin));
+    }
+  }
+}
+
+template <int MODE>
+static int launch_gemm(const float* A, const float* W, int B, int N, int K, const GemmEpi& ep, hipStream_t st) {
+  dim3 grid((N + 127) / 128, (B + 63) / 64);
+  hipLaunchKernelGGL(gemm_nt_f32_kernel<MODE>, grid, dim3(256), 0, st, A, W, B, N, K, ep);
+  FRMAP_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- row statistics: one wave per row ------------------------------------------------------------
+// mode 0: out[r] = 1 / max(||x_r||, eps)      mode 1: out[2r] = sum x^2, out[2r+1] = sum x
+__global__ void row_stats_kernel(const float* __restrict__ x, float* __restrict__ out, int R, int D, int mode, float eps) {
+  const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (r >= R) return;
+  float s2 = 0.f, s1 = 0.f;
+  for (int k = lane; k < D; k += 64) {
+    const float v = x[(size_t)r * D + k];
+    s2 += v * v;
+    s1 += v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s2 += __shfl_xor(s2, o, 64);
+    s1 += __shfl_xor(s1, o, 64);
+  }
+  if (lane == 0) {
+    if (mode == 0) out[r] = 1.0f / fmaxf(sqrtf(s2), eps);
+    else { out[2 * r] = s2; out[2 * r + 1] = s1; }
+  }
+}
+
+__global__ void l2_normalize_kernel(const float* __restrict__ x, float* __restrict__ out, int R, int D, float eps) {
+  const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (r >= R) return;
+  float s2 = 0.f;
+  for (int k = lane; k < D; k += 64) {
+    const float v = x[(size_t)r * D + k];
+    s2 += v * v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+  const float denom = fmaxf(sqrtf(s2), eps);
+  for (int k = lane; k < D; k += 64) out[(size_t)r * D + k] = x[(size_t)r * D + k] / denom;
+}
+
+__global__ void fill_u64_kernel(unsigned long long* p, int n, unsigned long long v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// exact distance of the winner, the way F.pairwise_distance forms it: ||(a - g) + eps||_2 in fp32
+__global__ void match_finalize_kernel(const float* __restrict__ emb, const float* __restrict__ gal,
+                                      const unsigned long long* __restrict__ keys, int32_t* __restrict__ idx_out,
+                                      float* __restrict__ dist_out, int B, int G, int D) {
+  const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (b >= B) return;
+  const unsigned long long key = keys[b];
+  if (G <= 0 || key == ~0ull) {
+    if (lane == 0) { idx_out[b] = -1; dist_out[b] = INFINITY; }
+    return;
+  }
+  const int g = (int)(key & 0xFFFFFFFFull);
+  float s2 = 0.f;
+  for (int k = lane; k < D; k += 64) {
+    const float d = (emb[(size_t)b * D + k] - gal[(size_t)g * D + k]) + 1e-6f;
+    s2 += d * d;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+  if (lane == 0) { idx_out[b] = g; dist_out[b] = sqrtf(s2); }
+}
+
+__global__ void argkey_finalize_kernel(const unsigned long long* __restrict__ keys, int32_t* __restrict__ out, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) out[b] = keys[b] ? (int32_t)(0xFFFFFFFFu - (unsigned)(keys[b] & 0xFFFFFFFFull)) : -1;
+}
+
+__global__ void minmax_init_kernel(unsigned int* k) {
+  k[0] = 0u;           // running max key
+  k[1] = 0xFFFFFFFFu;  // running min key
+}
+__global__ void minmax_finalize_kernel(const unsigned int* k, float* out) {
+  out[0] = f32_unordered(k[0]);
+  out[1] = f32_unordered(k[1]);
+}
+
+extern "C" size_t frmap_head_workspace_bytes(int B, int C) {
+  return (size_t)16 * ((size_t)(B > 0 ? B : 0) + (size_t)(C > 0 ? C : 0)) + 256;
+}
+
+static inline int waves_blocks(int rows) { return (rows + 3) / 4; }
+
+extern "C" int frmap_linear_f32(const float* x, const float* w, const float* scale, const float* shift, float* out,
+                                int B, int K, int N, int relu, void* stream) {
+  FRMAP_REQUIRE(x && w && out, "linear_f32: null pointer");
+  FRMAP_REQUIRE(B > 0 && K > 0 && N > 0 && K % 4 == 0, "linear_f32: bad shape B=%d K=%d N=%d (K %% 4 == 0)", B, K, N);
+  GemmEpi ep = {};
+  ep.scale = scale; ep.shift = shift; ep.relu = relu; ep.out = out;
+  return launch_gemm<MODE_LINEAR>(x, w, B, N, K, ep, (hipStream_t)stream);
+}
+
+extern "C" int frmap_l2_normalize_f32(const float* x, float* out, int B, int D, float eps, void* stream) {
+  FRMAP_REQUIRE(x && out, "l2_normalize: null pointer");
+  FRMAP_REQUIRE(B > 0 && D > 0, "l2_normalize: bad shape");
+  hipLaunchKernelGGL(l2_normalize_kernel, dim3(waves_blocks(B)), dim3(256), 0, (hipStream_t)stream, x, out, B, D, eps);
+  FRMAP_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int frmap_match_top1(const float* emb, const float* gallery, int32_t* idx_out, float* dist_out,
+                                void* workspace, int B, int G, int D, void* stream) {
+  FRMAP_REQUIRE(emb && idx_out && dist_out && workspace, "match_top1: null pointer");
+  FRMAP_REQUIRE(B > 0 && D > 0 && D % 4 == 0 && G >= 0, "match_top1: bad shape B=%d G=%d D=%d", B, G, D);
+  FRMAP_REQUIRE(G == 0 || gallery, "match_top1: null gallery");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned long long* keys = (unsigned long long*)workspace;
+  float* stat_a = (float*)(keys + B);
+  float* stat_w = stat_a + 2 * (size_t)B;
+  hipLaunchKernelGGL(fill_u64_kernel, dim3((B + 255) / 256), dim3(256), 0, st, keys, B, ~0ull);
+  if (G > 0) {
+    hipLaunchKernelGGL(row_stats_kernel, dim3(waves_blocks(B)), dim3(256), 0, st, emb, stat_a, B, D, 1, 0.f);
+    hipLaunchKernelGGL(row_stats_kernel, dim3(waves_blocks(G)), dim3(256), 0, st, gallery, stat_w, G, D, 1, 0.f);
+    GemmEpi ep = {};
+    ep.stat_a = stat_a; ep.stat_w = stat_w; ep.argkey = keys;
+    int rc = launch_gemm<MODE_DIST>(emb, gallery, B, G, D, ep, st);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(match_finalize_kernel, dim3(waves_blocks(B)), dim3(256), 0, st, emb, gallery, keys, idx_out, dist_out, B, G, D);
+  FRMAP_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int frmap_cosine_logits(const float* x, const float* w, float* logits_out, int32_t* argmax_out,
+                                   void* workspace, int B, int C, int D, float s, void* stream) {
+  FRMAP_REQUIRE(x && w && workspace && (logits_out || argmax_out), "cosine_logits: null pointer");
+  FRMAP_REQUIRE(B > 0 && C > 0 && D > 0 && D % 4 == 0, "cosine_logits: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned long long* keys = (unsigned long long*)workspace;
+  float* inv_a = (float*)(keys + B);
+  float* inv_w = inv_a + B;
+  hipLaunchKernelGGL(row_stats_kernel, dim3(waves_blocks(B)), dim3(256), 0, st, x, inv_a, B, D, 0, 1e-12f);
+  hipLaunchKernelGGL(row_stats_kernel, dim3(waves_blocks(C)), dim3(256), 0, st, w, inv_w, C, D, 0, 1e-12f);
+  GemmEpi ep = {};
+  ep.inv_a = inv_a; ep.inv_w = inv_w; ep.s = s; ep.out = logits_out;
+  if (argmax_out) {
+    hipLaunchKernelGGL(fill_u64_kernel, dim3((B + 255) / 256), dim3(256), 0, st, keys, B, 0ull);
+    ep.argkey = keys;
+  }
+  int rc = launch_gemm<MODE_COS>(x, w, B, C, D, ep, st);
+  if (rc) return rc;
+  if (argmax_out) hipLaunchKernelGGL(argkey_finalize_kernel, dim3((B + 255) / 256), dim3(256), 0, st, keys, argmax_out, B);
+  FRMAP_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int frmap_arcmargin_eval(const float* x, const float* w, const int64_t* label, float* logits_out,
+                                    float* minmax_out, void* workspace, int B, int C, int D, float s, float m,
+                                    int easy_margin, void* stream) {
+  FRMAP_REQUIRE(x && w && label && logits_out && workspace, "arcmargin_eval: null pointer");
+  FRMAP_REQUIRE(B > 0 && C > 0 && D > 0 && D % 4 == 0, "arcmargin_eval: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned int* mm = (unsigned int*)workspace;
+  float* inv_a = (float*)workspace + 4;
+  float* inv_w = inv_a + B;
+  hipLaunchKernelGGL(row_stats_kernel, dim3(waves_blocks(B)), dim3(256), 0, st, x, inv_a, B, D, 0, 1e-12f);
+  hipLaunchKernelGGL(row_stats_kernel, dim3(waves_blocks(C)), dim3(256), 0, st, w, inv_w, C, D, 0, 1e-12f);
+  GemmEpi ep = {};
+  ep.inv_a = inv_a; ep.inv_w = inv_w; ep.s = s < 24.0f ? s : 24.0f; ep.m = m; ep.easy = easy_margin;
+  ep.label = label; ep.out = logits_out;
+  if (minmax_out) {
+    hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, st, mm);
+    ep.minmax_key = mm;
+  }
+  int rc = launch_gemm<MODE_ARC>(x, w, B, C, D, ep, st);
+  if (rc) return rc;
+  if (minmax_out) hipLaunchKernelGGL(minmax_finalize_kernel, dim3(1), dim3(1), 0, st, mm, minmax_out);
+  FRMAP_LAUNCH_CHECK();
+  return 0;
+}

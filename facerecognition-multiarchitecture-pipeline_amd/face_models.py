@@ -1,0 +1,558 @@
+"""Host-side mirror of the reference model zoo's inference surface, computing on the HIP kernels.
+
+Same names, argument meaning, ``state_dict`` keys and error behaviour as
+``/root/reference/src/face_models.py`` for the hot path:
+
+* ``get_model(model_type, num_classes=18, input_size=(224, 224))``  (`face_models.py:785-813`)
+* ``BaselineNet`` (`:16-60`), ``ResNetTransfer`` (`:62-102`), ``SiameseNet`` (`:104-192`),
+  ``ArcMarginProduct`` eval (`:297-445`), ``ArcFaceNet`` eval (`:447-613`), ``HybridNet`` (`:650-721`)
+
+The modules are ordinary ``nn.Module`` parameter containers (so ``.to()``, ``.eval()``,
+``.state_dict()`` and ``load_state_dict()`` of a reference ``best_model.pth`` work), but
+``forward`` / ``get_embedding`` do not call ``torch.nn`` ops: they fold BatchNorm into the
+neighbouring conv / linear (fp32), pack the weights once into the kernels' layout, and launch the
+hand-written gfx950 kernels through the C ABI (``ops.py``).  Inputs must be fp32 NCHW tensors on
+the GPU and the module must be on the GPU and in ``eval()`` mode; anything else raises — there is
+no eager / CPU fallback.  Training (`face_models.py:527-572`, losses `:725-782`) is out of scope.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+MODEL_TYPES = ['baseline', 'cnn', 'siamese', 'attention', 'arcface', 'hybrid', 'ensemble']
+
+_DEFAULT_DTYPE = torch.bfloat16
+
+
+def set_default_compute_dtype(dtype: torch.dtype) -> None:
+    """bf16 (default; BASELINE.json's benchmark precision) or fp16 (the precision at which the
+    ≤1e-3 embedding-cosine bound of the north star is stated)."""
+    global _DEFAULT_DTYPE
+    ops.dt_code(dtype)
+    _DEFAULT_DTYPE = dtype
+
+
+# --------------------------------------------------------------------------------------------
+# folding helpers (fp32, one-off per weight version)
+# --------------------------------------------------------------------------------------------
+def _bn_scale_shift(bn: nn.Module, bias: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Eval BatchNorm as y = x*scale + shift; a preceding conv/linear bias is absorbed in shift."""
+    scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
+    if bias is not None:
+        shift = shift + bias.detach().float() * scale
+    return scale.contiguous(), shift.contiguous()
+
+
+class _PackedConv:
+    __slots__ = ("wpk", "shift", "cout", "k", "stride", "pad", "small")
+
+    def __init__(self, conv: nn.Conv2d, bn: Optional[nn.Module], dtype: torch.dtype):
+        w = conv.weight.detach().float()
+        if bn is not None:
+            scale, shift = _bn_scale_shift(bn, conv.bias)
+            w = w * scale.view(-1, 1, 1, 1)
+        else:
+            shift = conv.bias.detach().float() if conv.bias is not None else torch.zeros(w.shape[0], device=w.device)
+        self.cout, cin, kh, kw = w.shape
+        self.k, self.stride, self.pad = kh, conv.stride[0], conv.padding[0]
+        self.small = cin == 3
+        self.wpk = ops.pack_conv_weight_c3(w.contiguous(), dtype) if self.small else ops.pack_conv_weight(w.contiguous(), dtype)
+        self.shift = shift.contiguous()
+
+    def __call__(self, x: torch.Tensor, relu: bool, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self.small:
+            return ops.conv_small_cin(x, self.wpk, self.shift, self.cout, self.k, self.stride, self.pad, relu)
+        return ops.conv_igemm(x, self.wpk, self.shift, self.cout, self.k, self.stride, self.pad, relu, residual)
+
+
+class _PackedLinearAsConv:
+    """Wide nn.Linear (+BatchNorm1d) run on the MFMA conv kernel as a 1x1 conv over H=W=1."""
+    __slots__ = ("wpk", "shift", "cout")
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], bn: Optional[nn.Module], dtype: torch.dtype):
+        w = weight.detach().float()
+        if bn is not None:
+            scale, shift = _bn_scale_shift(bn, bias)
+            w = w * scale.view(-1, 1)
+        else:
+            shift = bias.detach().float() if bias is not None else torch.zeros(w.shape[0], device=w.device)
+        self.cout = w.shape[0]
+        self.wpk = ops.pack_conv_weight(w.reshape(w.shape[0], w.shape[1], 1, 1).contiguous(), dtype)
+        self.shift = shift.contiguous()
+
+    def __call__(self, x2d: torch.Tensor, relu: bool) -> torch.Tensor:
+        B, K = x2d.shape
+        y = ops.conv_igemm(x2d.view(B, 1, 1, K), self.wpk, self.shift, self.cout, 1, 1, 0, relu, None)
+        return y.view(B, self.cout)
+
+
+# --------------------------------------------------------------------------------------------
+# base class: plan cache + input checks
+# --------------------------------------------------------------------------------------------
+class _HipModule(nn.Module):
+    """nn.Module whose inference runs on the HIP kernels.  The packed-weight "plan" is rebuilt
+    whenever a parameter/buffer is replaced, moved or modified in place (tensor version counters)."""
+
+    def __init__(self):
+        super().__init__()
+        self._plan = None
+        self._plan_sig = None
+        self.compute_dtype = _DEFAULT_DTYPE
+
+    def set_compute_dtype(self, dtype: torch.dtype):
+        ops.dt_code(dtype)
+        self.compute_dtype = dtype
+        self._plan = None
+        return self
+
+    def _signature(self):
+        sig = [self.compute_dtype]
+        for t in list(self.parameters()) + list(self.buffers()):
+            sig.append((t.data_ptr(), t._version))
+        return tuple(sig)
+
+    def _get_plan(self):
+        sig = self._signature()
+        if self._plan is None or sig != self._plan_sig:
+            dev = next(self.parameters()).device
+            if dev.type != "cuda":
+                raise RuntimeError(f"{type(self).__name__} is on {dev}; move it to the GPU (.to('cuda')) — "
+                                   "the HIP path has no CPU fallback")
+            with torch.no_grad():
+                self._plan = self._build_plan(self.compute_dtype)
+            self._plan_sig = self._signature()
+        return self._plan
+
+    def _build_plan(self, dtype):  # pragma: no cover - abstract
+        raise NotImplementedError
+
+    def _check_input(self, x: torch.Tensor) -> torch.Tensor:
+        if not isinstance(x, torch.Tensor) or x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError(f"expected a B×3×H×W tensor, got {tuple(x.shape) if isinstance(x, torch.Tensor) else type(x)}")
+        if not x.is_cuda:
+            raise RuntimeError("input is on the CPU; the HIP path needs GPU tensors (no CPU fallback)")
+        if self.training:
+            raise NotImplementedError(f"{type(self).__name__}: only eval-mode inference is implemented on the HIP path; "
+                                      "call .eval() (training is out of scope, SURVEY.md §2.1)")
+        return x.float() if x.dtype != torch.float32 else x
+
+
+# --------------------------------------------------------------------------------------------
+# ResNet-18 parameter container with torchvision's attribute names / order
+# (torchvision is un-vendored; call sites face_models.py:67,269,463,658)
+# --------------------------------------------------------------------------------------------
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes: int, planes: int, stride: int = 1, downsample: Optional[nn.Module] = None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        raise RuntimeError("BasicBlock is a parameter container; inference runs through the owning HIP module")
+
+
+class ResNet18(nn.Module):
+    """Parameter container: ``conv1 bn1 relu maxpool layer1..4 avgpool fc`` (children order matters —
+    the reference slices ``children()[:-1]`` / ``[:-2]``, `face_models.py:100,464,660`)."""
+
+    def __init__(self, num_classes: int = 1000):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        inpl = 64
+        for i, (planes, stride) in enumerate(((64, 1), (128, 2), (256, 2), (512, 2)), start=1):
+            ds = None
+            if stride != 1 or inpl != planes:
+                ds = nn.Sequential(nn.Conv2d(inpl, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+            setattr(self, f"layer{i}", nn.Sequential(BasicBlock(inpl, planes, stride, ds), BasicBlock(planes, planes)))
+            inpl = planes
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(512, num_classes)
+
+    def forward(self, x):
+        raise RuntimeError("ResNet18 is a parameter container; inference runs through the owning HIP module")
+
+
+class _TrunkPlan:
+    """Packed ResNet-18 trunk: stem conv → maxpool → 8 BasicBlocks (→ global average pool)."""
+
+    def __init__(self, rn: ResNet18, dtype: torch.dtype):
+        self.dtype = dtype
+        self.stem = _PackedConv(rn.conv1, rn.bn1, dtype)
+        self.blocks = []
+        for li in range(1, 5):
+            for blk in getattr(rn, f"layer{li}"):
+                ds = _PackedConv(blk.downsample[0], blk.downsample[1], dtype) if blk.downsample is not None else None
+                self.blocks.append((_PackedConv(blk.conv1, blk.bn1, dtype), _PackedConv(blk.conv2, blk.bn2, dtype), ds))
+
+    def features(self, x: torch.Tensor) -> torch.Tensor:
+        """fp32 NCHW → NHWC B×7×7×512 (for 224² input) in the compute dtype."""
+        x = ops.pack_input(x, self.dtype)
+        x = self.stem(x, relu=True)
+        x = ops.maxpool(x, 3, 2, 1)
+        for c1, c2, ds in self.blocks:
+            idn = ds(x, relu=False) if ds is not None else x
+            x = c2(c1(x, relu=True), relu=True, residual=idn)
+        return x
+
+    def pooled(self, x: torch.Tensor) -> torch.Tensor:
+        return ops.avgpool_global(self.features(x))  # fp32 B×512
+
+
+# --------------------------------------------------------------------------------------------
+# a2  BaselineNet
+# --------------------------------------------------------------------------------------------
+class BaselineNet(_HipModule):
+    """`face_models.py:16-60`."""
+
+    def __init__(self, num_classes: int = 18, input_size: Tuple[int, int] = (224, 224)):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 32, 3, padding=1)
+        self.bn1 = nn.BatchNorm2d(32)
+        self.conv2 = nn.Conv2d(32, 64, 3, padding=1)
+        self.bn2 = nn.BatchNorm2d(64)
+        self.conv3 = nn.Conv2d(64, 128, 3, padding=1)
+        self.bn3 = nn.BatchNorm2d(128)
+        self.pool = nn.MaxPool2d(2, 2)
+        self.adaptive_pool = nn.AdaptiveAvgPool2d(1)
+        self.fc1 = nn.Linear(128, 512)
+        self.fc2 = nn.Linear(512, num_classes)
+        self.dropout = nn.Dropout(0.5)
+
+    def _build_plan(self, dtype):
+        return {"c1": _PackedConv(self.conv1, self.bn1, dtype), "c2": _PackedConv(self.conv2, self.bn2, dtype),
+                "c3": _PackedConv(self.conv3, self.bn3, dtype)}
+
+    def get_embedding(self, x):
+        x = self._check_input(x)
+        p = self._get_plan()
+        x = ops.pack_input(x, self.compute_dtype)
+        x = ops.maxpool(p["c1"](x, relu=True), 2, 2, 0)
+        x = ops.maxpool(p["c2"](x, relu=True), 2, 2, 0)
+        x = ops.maxpool(p["c3"](x, relu=True), 2, 2, 0)
+        f = ops.avgpool_global(x)
+        return ops.linear_f32(f, self.fc1.weight.detach(), None, self.fc1.bias.detach(), relu=True)
+
+    def forward(self, x):
+        e = self.get_embedding(x)
+        return ops.linear_f32(e, self.fc2.weight.detach(), None, self.fc2.bias.detach())
+
+
+# --------------------------------------------------------------------------------------------
+# a3  ResNetTransfer ('cnn')
+# --------------------------------------------------------------------------------------------
+class ResNetTransfer(_HipModule):
+    """`face_models.py:62-102`.  No pretrained-weight fetch (offline); load a checkpoint instead."""
+
+    def __init__(self, num_classes: int = 18, freeze_backbone: bool = False):
+        super().__init__()
+        self.resnet = ResNet18()
+        in_feats = self.resnet.fc.in_features
+        self.dropout = nn.Dropout(0.1)
+        self.resnet.fc = nn.Sequential(self.dropout, nn.Linear(in_feats, num_classes))
+        if freeze_backbone:
+            self._freeze_backbone()
+
+    def _freeze_backbone(self):
+        for name, param in self.resnet.named_parameters():
+            if "fc" not in name:
+                param.requires_grad = False
+
+    def unfreeze_backbone(self):
+        for param in self.resnet.parameters():
+            param.requires_grad = True
+
+    def _build_plan(self, dtype):
+        return _TrunkPlan(self.resnet, dtype)
+
+    def forward(self, x):
+        x = self._check_input(x)
+        f = self._get_plan().pooled(x)
+        fc = self.resnet.fc[1]
+        return ops.linear_f32(f, fc.weight.detach(), None, fc.bias.detach())
+
+    def get_embedding(self, x):
+        x = self._check_input(x)
+        return self._get_plan().pooled(x).squeeze()  # `.squeeze()` as the reference (`:102`): (512,) at B == 1
+
+
+# --------------------------------------------------------------------------------------------
+# a6  SiameseNet
+# --------------------------------------------------------------------------------------------
+class SiameseNet(_HipModule):
+    """`face_models.py:104-192`."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv = nn.Sequential(
+            nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3), nn.BatchNorm2d(64), nn.ReLU(inplace=True),
+            nn.MaxPool2d(2, stride=2),
+            nn.Conv2d(64, 128, kernel_size=3, padding=1), nn.BatchNorm2d(128), nn.ReLU(inplace=True),
+            nn.Conv2d(128, 128, kernel_size=3, padding=1), nn.BatchNorm2d(128), nn.ReLU(inplace=True),
+            nn.MaxPool2d(2, stride=2),
+            nn.Conv2d(128, 256, kernel_size=3, padding=1), nn.BatchNorm2d(256), nn.ReLU(inplace=True),
+            nn.Conv2d(256, 256, kernel_size=3, padding=1), nn.BatchNorm2d(256), nn.ReLU(inplace=True),
+            nn.MaxPool2d(2, stride=2),
+            nn.Conv2d(256, 512, kernel_size=3, padding=1), nn.BatchNorm2d(512), nn.ReLU(inplace=True),
+            nn.AdaptiveAvgPool2d((6, 6)),
+        )
+        self.fc = nn.Sequential(
+            nn.Dropout(0.3), nn.Linear(512 * 6 * 6, 1024), nn.BatchNorm1d(1024), nn.ReLU(inplace=True),
+            nn.Dropout(0.2), nn.Linear(1024, 512), nn.BatchNorm1d(512), nn.ReLU(inplace=True),
+            nn.Linear(512, 256),
+        )
+        self.debug_shapes = {}
+
+    def _build_plan(self, dtype):
+        c = self.conv
+        # fc.1 consumes the NCHW flatten (index c*36 + s, `face_models.py:171`); our pooled tensor is
+        # NHWC (index s*512 + c): permute the weight's input axis once here.
+        w1 = self.fc[1].weight.detach().float().view(1024, 512, 36).permute(0, 2, 1).reshape(1024, 36 * 512)
+        return {
+            "convs": [(_PackedConv(c[0], c[1], dtype), True), (_PackedConv(c[4], c[5], dtype), False),
+                      (_PackedConv(c[7], c[8], dtype), True), (_PackedConv(c[11], c[12], dtype), False),
+                      (_PackedConv(c[14], c[15], dtype), True), (_PackedConv(c[18], c[19], dtype), False)],
+            "fc1": _PackedLinearAsConv(w1, self.fc[1].bias, self.fc[2], dtype),
+            "fc2": _PackedLinearAsConv(self.fc[5].weight, self.fc[5].bias, self.fc[6], dtype),
+            "fc3": _PackedLinearAsConv(self.fc[8].weight, self.fc[8].bias, None, dtype),
+        }
+
+    def forward_one(self, x):
+        x = self._check_input(x)
+        p = self._get_plan()
+        batch_size = x.size(0)
+        self.debug_shapes["input"] = x.shape
+        x = ops.pack_input(x, self.compute_dtype)
+        for conv, pool in p["convs"]:
+            x = conv(x, relu=True)
+            if pool:
+                x = ops.maxpool(x, 2, 2, 0)
+        x = ops.avgpool_adaptive(x, 6, 6)  # NHWC B×6×6×512
+        self.debug_shapes["after_conv"] = torch.Size((batch_size, 512, 6, 6))
+        feats = x.view(batch_size, -1)
+        self.debug_shapes["flattened"] = feats.shape
+        feats = p["fc3"](p["fc2"](p["fc1"](feats, relu=True), relu=True), relu=False)
+        self.debug_shapes["before_norm"] = feats.shape
+        return ops.l2_normalize(ops.cast_to_f32(feats), 1e-12)
+
+    def forward(self, x1, x2):
+        return self.forward_one(x1), self.forward_one(x2)
+
+    def get_embedding(self, x):
+        return self.forward_one(x)
+
+    def get_debug_info(self):
+        return self.debug_shapes
+
+
+# --------------------------------------------------------------------------------------------
+# a5  ArcMarginProduct (eval)      a4  ArcFaceNet (eval)
+# --------------------------------------------------------------------------------------------
+class ArcMarginProduct(nn.Module):
+    """`face_models.py:297-445`; only the eval-mode forward is implemented (margin = m, scale =
+    min(s, 24), `:369,401-404`)."""
+
+    def __init__(self, in_feats, out_feats, s=32.0, m=0.5, use_warm_up=True, easy_margin=False):
+        super().__init__()
+        self.in_feats, self.out_feats = in_feats, out_feats
+        self.s, self.m, self.easy_margin = s, m, easy_margin
+        self.use_warm_up = use_warm_up
+        self.warm_up_epochs = 10
+        self.margin_factor = 0.0
+        self.scale_factor = 0.3
+        self.current_epoch = 0
+        self.weight = nn.Parameter(torch.empty(out_feats, in_feats))
+        nn.init.xavier_normal_(self.weight, gain=math.sqrt(2))
+        self.register_buffer('u', torch.zeros(1))
+        self.max_cos_theta = 0.0
+        self.min_cos_theta = 0.0
+        self.easy_margin_used = False
+        self._minmax = None
+
+    def forward(self, input, label):
+        if self.training:
+            raise NotImplementedError("ArcMarginProduct: the training-mode margin schedule (face_models.py:336-348,"
+                                      "404-420) is out of scope; call .eval()")
+        if self.easy_margin:
+            self.easy_margin_used = True
+        out, mm = ops.arcmargin_eval(input.float(), self.weight.detach(), label, self.s, self.m, self.easy_margin,
+                                     want_minmax=True)
+        self._minmax = mm  # fetched lazily: the reference's two .item() syncs (`:358-360`) are not forced here
+        return out
+
+    def _sync_minmax(self):
+        if self._minmax is not None:
+            mx, mn = self._minmax.tolist()
+            self.max_cos_theta, self.min_cos_theta = mx, mn
+            self._minmax = None
+
+    def update_epoch(self, epoch):
+        self.current_epoch = epoch
+
+    def get_margin_stats(self):
+        self._sync_minmax()
+        return {'margin_factor': self.margin_factor, 'scale_factor': self.scale_factor,
+                'effective_margin': self.m * self.margin_factor, 'effective_scale': self.s * self.scale_factor,
+                'max_cos_theta': self.max_cos_theta, 'min_cos_theta': self.min_cos_theta,
+                'easy_margin_used': self.easy_margin_used if self.easy_margin else False}
+
+
+class ArcFaceNet(_HipModule):
+    """`face_models.py:447-613` (eval branch `:573-582`, ``get_embedding`` `:584-590`)."""
+
+    def __init__(self, num_classes=18, dropout_rate=0.2, s=32.0, m=0.5, easy_margin=False):
+        super().__init__()
+        self.backbone = ResNet18()
+        self.features = nn.Sequential(*list(self.backbone.children())[:-1])
+        self.embedding = nn.Linear(512, 512, bias=False)
+        self.bn = nn.BatchNorm1d(512, eps=1e-5)
+        self.dropout = nn.Dropout(p=dropout_rate)
+        self.arcface = ArcMarginProduct(512, num_classes, s=s, m=m, use_warm_up=True, easy_margin=easy_margin)
+        self.last_grad_norm = 0.0
+        self.max_grad_norm = 1.0
+        self.current_epoch = 0
+        self.phase = 1
+        self.backbone_frozen = False
+        self.val_classifier = nn.Linear(512, num_classes)
+        nn.init.xavier_normal_(self.val_classifier.weight, gain=math.sqrt(2))
+
+    def freeze_backbone(self):
+        self.backbone_frozen = True
+        self.phase = 1
+        for param_name, param in self.named_parameters():
+            if 'backbone' in param_name or 'features' in param_name:
+                param.requires_grad = False
+
+    def unfreeze_backbone(self):
+        self.backbone_frozen = False
+        self.phase = 2
+        for param in self.parameters():
+            param.requires_grad = True
+
+    def set_max_grad_norm(self, max_norm):
+        self.max_grad_norm = max_norm
+
+    def _build_plan(self, dtype):
+        scale, shift = _bn_scale_shift(self.bn)
+        return {"trunk": _TrunkPlan(self.backbone, dtype), "bn_scale": scale, "bn_shift": shift}
+
+    def _pre_norm(self, x):
+        p = self._get_plan()
+        f = p["trunk"].pooled(x)
+        return ops.linear_f32(f, self.embedding.weight.detach(), p["bn_scale"], p["bn_shift"])
+
+    def get_embedding(self, x):
+        x = self._check_input(x)
+        return ops.l2_normalize(self._pre_norm(x), 1e-12)
+
+    def forward(self, x, labels=None):
+        if self.training:
+            if labels is None:
+                raise ValueError("Labels must be provided during training")
+            raise NotImplementedError("ArcFaceNet: the training branch (face_models.py:527-572) is out of scope")
+        emb = self.get_embedding(x)
+        # `face_models.py:576`: the classifier rows are re-normalised in place on every eval call
+        if self.val_classifier.weight.is_cuda:
+            self.val_classifier.weight.data.copy_(ops.l2_normalize(self.val_classifier.weight.data, 1e-12))
+        if labels is not None:
+            return ops.linear_f32(emb, self.val_classifier.weight.detach(), None, self.val_classifier.bias.detach())
+        return emb
+
+    def update_epoch(self, epoch):
+        self.current_epoch = epoch
+        self.arcface.update_epoch(epoch)
+
+    def get_arcface_stats(self):
+        stats = self.arcface.get_margin_stats()
+        stats.update(grad_norm=self.last_grad_norm, max_grad_norm=self.max_grad_norm, phase=self.phase,
+                     backbone_frozen=self.backbone_frozen)
+        return stats
+
+    def get_training_phase(self):
+        return {'phase': self.phase, 'backbone_frozen': self.backbone_frozen, 'epoch': self.current_epoch}
+
+
+# --------------------------------------------------------------------------------------------
+# a7  HybridNet (+ TransformerBlock)  — parameter containers; device path lands with the
+#     transformer kernels
+# --------------------------------------------------------------------------------------------
+class TransformerBlock(nn.Module):
+    """`face_models.py:618-648` (parameter container)."""
+
+    def __init__(self, embed_dim, num_heads=4, ff_dim=2048, dropout=0.1):
+        super().__init__()
+        self.attention = nn.MultiheadAttention(embed_dim, num_heads, dropout=dropout)
+        self.norm1 = nn.LayerNorm(embed_dim)
+        self.norm2 = nn.LayerNorm(embed_dim)
+        self.ff = nn.Sequential(nn.Linear(embed_dim, ff_dim), nn.GELU(), nn.Dropout(dropout),
+                                nn.Linear(ff_dim, embed_dim), nn.Dropout(dropout))
+
+    def forward(self, x):
+        raise RuntimeError("TransformerBlock is a parameter container; inference runs through HybridNet")
+
+
+class HybridNet(_HipModule):
+    """`face_models.py:650-721`."""
+
+    def __init__(self, num_classes=18):
+        super().__init__()
+        self.cnn = ResNet18()
+        self.features = nn.Sequential(*list(self.cnn.children())[:-2])
+        self.fdim = 512
+        self.seq_len = 49
+        self.pos_encoding = nn.Parameter(torch.zeros(self.seq_len, 1, self.fdim))
+        nn.init.normal_(self.pos_encoding, mean=0, std=0.02)
+        self.transformer = TransformerBlock(self.fdim)
+        self.dropout = nn.Dropout(0.1)
+        self.norm = nn.LayerNorm(self.fdim)
+        self.fc = nn.Linear(self.fdim, num_classes)
+
+    def _build_plan(self, dtype):
+        return {"trunk": _TrunkPlan(self.cnn, dtype)}
+
+    def get_embedding(self, x):
+        raise NotImplementedError("HybridNet: the transformer block kernels are not built yet (SURVEY.md §7 step 8); "
+                                  "the ResNet trunk is available via ResNetTransfer / ArcFaceNet")
+
+    def forward(self, x):
+        return self.get_embedding(x)
+
+
+# --------------------------------------------------------------------------------------------
+# a1  factory
+# --------------------------------------------------------------------------------------------
+def get_model(model_type: str, num_classes: int = 18, input_size: Tuple[int, int] = (224, 224)) -> nn.Module:
+    """`face_models.py:785-813`: same type strings; unknown → ``ValueError``.  Returns a train-mode
+    module on the CPU with fp32 parameters, as the reference does; ``.to('cuda').eval()`` before
+    inference.  'attention' / 'ensemble' (and list inputs) are valid names in the reference but are
+    outside this build's hot-path scope and raise ``NotImplementedError``."""
+    if model_type == 'baseline':
+        return BaselineNet(num_classes=num_classes, input_size=input_size)
+    elif model_type == 'cnn':
+        return ResNetTransfer(num_classes=num_classes, freeze_backbone=False)
+    elif model_type == 'siamese':
+        return SiameseNet()
+    elif model_type == 'arcface':
+        return ArcFaceNet(num_classes=num_classes, dropout_rate=0.2)
+    elif model_type == 'hybrid':
+        return HybridNet(num_classes=num_classes)
+    elif model_type in ('attention', 'ensemble') or isinstance(model_type, list):
+        raise NotImplementedError(f"model type {model_type!r} is outside the MI355X hot-path scope (SURVEY.md §2.2)")
+    else:
+        raise ValueError(f"Invalid model type: {model_type}")

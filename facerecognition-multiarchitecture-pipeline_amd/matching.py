@@ -1,0 +1,175 @@
+"""Gallery matching with the reference's call surface, computed on the GPU.
+
+Mirrors ``/root/reference/src/app.py``:
+
+* ``compare_faces(emb, refs, thresh) -> (name, dist, idx|None)``  (`app.py:50-64`): Euclidean
+  ``F.pairwise_distance`` (eps = 1e-6 added to the *difference*), first strict minimum, the
+  ``("Unknown", dist, None)`` result above the threshold and the ``("Unknown", inf, None)``
+  sentinel for ``None`` / empty input — never raises on those.
+* ``load_refs()`` / ``save_refs(refs)``  (`app.py:67-123`): same pickle file layout, entries whose
+  image file is missing are dropped on load; the file is read with a non-executing parser
+  (``gallery_io``), not ``pickle.load``.
+* ``embed_and_match(model, x, gallery, thresh)``: the batched form: for every b,
+  ``ids[b], dists[b] == compare_faces(model(x[b:b+1]), refs, thresh)[2], [1]``.
+
+The per-entry Python loop of the reference becomes one fp32 MFMA kernel
+(``frmap_match_top1``) over a device-resident G×D gallery matrix.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import gallery_io, ops
+
+REC_THRESH = 1.0                       # `app.py:20`
+REF_DIR = "face_references"            # `app.py:23`
+REF_FILE = os.path.join(REF_DIR, "face_references.pkl")   # `app.py:24`
+_save_counter = 0
+
+
+class Gallery:
+    """Device-resident gallery: names + one fp32 G×D matrix (row i = reference i's embedding)."""
+
+    def __init__(self, names: Sequence[str], embeddings: torch.Tensor, device: Union[str, torch.device] = "cuda"):
+        emb = embeddings.detach().to(torch.float32)
+        if emb.dim() == 3 and emb.shape[1] == 1:
+            emb = emb[:, 0, :]
+        if emb.dim() != 2 or emb.shape[0] != len(names):
+            raise ValueError("Gallery: need one D-vector per name")
+        self.names = list(names)
+        self.matrix = emb.to(device).contiguous()
+
+    @classmethod
+    def from_refs(cls, refs: Sequence[dict], device: Union[str, torch.device] = "cuda") -> "Gallery":
+        if not refs:
+            return cls([], torch.zeros((0, 1)), device)
+        rows = [r["embedding"].detach().reshape(-1).to(torch.float32).cpu() for r in refs]
+        return cls([r["name"] for r in refs], torch.stack(rows), device)
+
+    def __len__(self):
+        return len(self.names)
+
+
+_gallery_cache: dict = {}
+
+
+def _as_gallery(refs, device) -> Gallery:
+    if isinstance(refs, Gallery):
+        return refs
+    # the demo passes the same list object every frame (`app.py:639`); cache on identity + content tag
+    key = id(refs)
+    tag = (len(refs), tuple(id(r.get("embedding")) for r in refs))
+    hit = _gallery_cache.get(key)
+    if hit is not None and hit[0] == tag and hit[1].matrix.device == torch.device(device):
+        return hit[1]
+    g = Gallery.from_refs(refs, device)
+    if len(_gallery_cache) > 8:
+        _gallery_cache.clear()
+    _gallery_cache[key] = (tag, g)
+    return g
+
+
+def match_batch(emb: torch.Tensor, gallery: Gallery) -> Tuple[torch.Tensor, torch.Tensor]:
+    """B×D device embeddings → (int32[B] first-arg-min index, fp32[B] distance), on the device."""
+    return ops.match_top1(emb.to(torch.float32), gallery.matrix)
+
+
+def compare_faces(emb, refs, thresh):
+    """`app.py:50-64` on the GPU."""
+    if emb is None or refs is None or len(refs) == 0:
+        return "Unknown", float('inf'), None
+    dev = emb.device if emb.is_cuda else torch.device("cuda")
+    g = _as_gallery(refs, dev)
+    e = emb.detach().reshape(1, -1).to(device=dev, dtype=torch.float32)
+    idx, dist = match_batch(e, g)
+    best_ref_idx = int(idx.item())
+    min_dist = float(dist.item())
+    if min_dist <= thresh:
+        return g.names[best_ref_idx], min_dist, best_ref_idx
+    return "Unknown", min_dist, None
+
+
+def embed_and_match(model, x: torch.Tensor, gallery, thresh: float = REC_THRESH,
+                    normalize: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Embed a batch and match every face.  Returns ``(ids int32[B], dists fp32[B])`` on the device,
+    ``ids[b] = -1`` where the best distance exceeds ``thresh`` (compare_faces' "Unknown").
+    ``normalize=True`` L2-normalises the embeddings first (for models whose embedding is not
+    unit-norm: 'baseline', 'cnn', 'hybrid')."""
+    emb = model.get_embedding(x)
+    if emb.dim() == 1:
+        emb = emb.unsqueeze(0)
+    if normalize:
+        emb = ops.l2_normalize(emb, 1e-12)
+    g = _as_gallery(gallery, emb.device)
+    idx, dist = match_batch(emb, g)
+    ids = torch.where(dist <= thresh, idx, torch.full_like(idx, -1))
+    return ids, dist
+
+
+# ------------------------------------------------------------------------------------------------
+# persistence (`app.py:67-123`)
+# ------------------------------------------------------------------------------------------------
+def _imread_bgr(path: str):
+    try:
+        from PIL import Image
+        with Image.open(path) as im:
+            return np.asarray(im.convert("RGB"))[:, :, ::-1].copy()
+    except Exception:
+        return None
+
+
+def _imwrite_bgr(path: str, img) -> bool:
+    try:
+        from PIL import Image
+        Image.fromarray(np.asarray(img)[:, :, ::-1]).save(path)
+        return True
+    except Exception:
+        return False
+
+
+def load_refs(ref_file: Optional[str] = None) -> List[dict]:
+    """`app.py:104-123`: ``[]`` if the file is missing or unreadable; entries whose image is missing
+    are skipped; embeddings come back as CPU fp32 tensors."""
+    ref_file = ref_file or REF_FILE
+    if not os.path.exists(ref_file):
+        return []
+    refs = []
+    try:
+        for rec in gallery_io.read_gallery_file(ref_file):
+            p = rec["image_path"]
+            if p and not os.path.isabs(p) and not os.path.exists(p):
+                alt = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(ref_file))), p)
+                p = alt if os.path.exists(alt) else p
+            if p and os.path.exists(p):
+                img = _imread_bgr(p)
+                if img is not None:
+                    refs.append({'name': rec['name'], 'embedding': torch.tensor(rec['embedding_numpy']).cpu(),
+                                 'image': img})
+        return refs
+    except Exception:
+        return []
+
+
+def save_refs(refs: Sequence[dict], ref_file: Optional[str] = None) -> bool:
+    """`app.py:67-91`: one JPEG per entry (``<name>_<counter:08x>.jpg``) + the pickle list."""
+    global _save_counter
+    ref_file = ref_file or REF_FILE
+    ref_dir = os.path.dirname(os.path.abspath(ref_file))
+    try:
+        os.makedirs(ref_dir, exist_ok=True)
+        records = []
+        for ref in refs:
+            _save_counter += 1
+            img_file = f"{ref['name'].replace(' ', '_')}_{_save_counter:08x}.jpg"
+            img_path = os.path.join(ref_dir, img_file)
+            if _imwrite_bgr(img_path, ref['image']):
+                records.append({'name': ref['name'], 'embedding_numpy': ref['embedding'].detach().cpu().numpy(),
+                                'image_path': img_path})
+        gallery_io.write_gallery_file(ref_file, records)
+        return True
+    except Exception:
+        return False

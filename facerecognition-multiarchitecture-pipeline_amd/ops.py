@@ -1,0 +1,234 @@
+"""Thin tensor-level wrappers over the C ABI (``include/frmap_hip.h``).
+
+PyTorch is used here only for device memory (``torch.empty``) and the current HIP stream; every
+function validates that its operands live on the GPU and hands raw pointers to the library.
+Activations are NHWC tensors in the compute dtype (bf16 / fp16); heads and matching are fp32.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+BF16, F16 = 0, 1
+_DT = {torch.bfloat16: BF16, torch.float16: F16}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, what: str, dtype=None) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{what}: expected a tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: tensor is on {t.device}; the HIP path needs GPU tensors (no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{what}: expected dtype {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def dt_code(dtype: torch.dtype) -> int:
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise TypeError(f"compute dtype must be torch.bfloat16 or torch.float16, got {dtype}") from None
+
+
+def pack_input(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """fp32 NCHW B×3×H×W -> NHWC4 (zero 4th channel) in ``dtype``."""
+    x = _dev(x, "pack_input.x", torch.float32)
+    if x.dim() != 4 or x.shape[1] != 3:
+        raise ValueError(f"expected B×3×H×W input, got {tuple(x.shape)}")
+    B, _, H, W = x.shape
+    out = torch.empty((B, H, W, 4), dtype=dtype, device=x.device)
+    _lib.check(_lib.load().frmap_pack_input_nchw_f32(x.data_ptr(), out.data_ptr(), B, H, W, dt_code(dtype), _stream()),
+               "pack_input")
+    return out
+
+
+def pack_conv_weight(w_folded: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    w = _dev(w_folded, "pack_conv_weight.w", torch.float32)
+    Cout, Cin, KH, KW = w.shape
+    out = torch.empty((Cout * Cin * KH * KW,), dtype=dtype, device=w.device)
+    _lib.check(_lib.load().frmap_pack_conv_weight(w.data_ptr(), out.data_ptr(), Cout, Cin, KH, KW, dt_code(dtype),
+                                                  _stream()), "pack_conv_weight")
+    return out
+
+
+def pack_conv_weight_c3(w_folded: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    w = _dev(w_folded, "pack_conv_weight_c3.w", torch.float32)
+    Cout, Cin, KH, KW = w.shape
+    if Cin != 3:
+        raise ValueError("pack_conv_weight_c3: Cin must be 3")
+    lib = _lib.load()
+    out = torch.empty((Cout * lib.frmap_small_cin_kpad(KH, KW),), dtype=dtype, device=w.device)
+    _lib.check(lib.frmap_pack_conv_weight_c3(w.data_ptr(), out.data_ptr(), Cout, KH, KW, dt_code(dtype), _stream()),
+               "pack_conv_weight_c3")
+    return out
+
+
+def conv_small_cin(x4: torch.Tensor, wpk: torch.Tensor, shift: torch.Tensor, Cout: int, k: int, stride: int,
+                   pad: int, relu: bool) -> torch.Tensor:
+    x4 = _dev(x4, "conv_small_cin.x")
+    B, H, W, C = x4.shape
+    if C != 4:
+        raise ValueError("conv_small_cin: input must be NHWC4")
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out = torch.empty((B, Ho, Wo, Cout), dtype=x4.dtype, device=x4.device)
+    _lib.check(_lib.load().frmap_conv_small_cin(x4.data_ptr(), _dev(wpk, "wpk").data_ptr(),
+                                                _dev(shift, "shift", torch.float32).data_ptr(), out.data_ptr(),
+                                                B, H, W, Cout, k, k, stride, pad, int(relu), dt_code(x4.dtype),
+                                                _stream()), "conv_small_cin")
+    return out
+
+
+def conv_igemm(x: torch.Tensor, wpk: torch.Tensor, shift: torch.Tensor, Cout: int, k: int, stride: int, pad: int,
+               relu: bool, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    x = _dev(x, "conv_igemm.x")
+    B, H, W, Cin = x.shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out = torch.empty((B, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
+    res_ptr = 0
+    if residual is not None:
+        residual = _dev(residual, "conv_igemm.residual", x.dtype)
+        if tuple(residual.shape) != tuple(out.shape):
+            raise ValueError(f"conv_igemm: residual shape {tuple(residual.shape)} != output {tuple(out.shape)}")
+        res_ptr = residual.data_ptr()
+    if wpk.numel() != Cout * Cin * k * k or wpk.dtype != x.dtype:
+        raise ValueError("conv_igemm: packed weight does not match Cout*Cin*k*k / dtype")
+    if shift.numel() != Cout:
+        raise ValueError("conv_igemm: shift must have Cout elements")
+    _lib.check(_lib.load().frmap_conv_igemm(x.data_ptr(), _dev(wpk, "wpk").data_ptr(),
+                                            _dev(shift, "shift", torch.float32).data_ptr(), res_ptr, out.data_ptr(),
+                                            B, H, W, Cin, Cout, k, stride, pad, int(relu), dt_code(x.dtype),
+                                            _stream()), "conv_igemm")
+    return out
+
+
+def maxpool(x: torch.Tensor, k: int, stride: int, pad: int) -> torch.Tensor:
+    x = _dev(x, "maxpool.x")
+    B, H, W, Cc = x.shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out = torch.empty((B, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().frmap_maxpool(x.data_ptr(), out.data_ptr(), B, H, W, Cc, k, stride, pad, dt_code(x.dtype),
+                                         _stream()), "maxpool")
+    return out
+
+
+def avgpool_global(x: torch.Tensor) -> torch.Tensor:
+    x = _dev(x, "avgpool_global.x")
+    B, H, W, Cc = x.shape
+    out = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().frmap_avgpool_global(x.data_ptr(), out.data_ptr(), B, H * W, Cc, dt_code(x.dtype),
+                                                _stream()), "avgpool_global")
+    return out
+
+
+def avgpool_adaptive(x: torch.Tensor, OH: int, OW: int) -> torch.Tensor:
+    x = _dev(x, "avgpool_adaptive.x")
+    B, H, W, Cc = x.shape
+    out = torch.empty((B, OH, OW, Cc), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().frmap_avgpool_adaptive(x.data_ptr(), out.data_ptr(), B, H, W, Cc, OH, OW,
+                                                  dt_code(x.dtype), _stream()), "avgpool_adaptive")
+    return out
+
+
+def linear_f32(x: torch.Tensor, w: torch.Tensor, scale: Optional[torch.Tensor] = None,
+               shift: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
+    x = _dev(x, "linear_f32.x", torch.float32)
+    w = _dev(w, "linear_f32.w", torch.float32)
+    B, K = x.shape
+    N, K2 = w.shape
+    if K != K2:
+        raise ValueError(f"linear_f32: x is B×{K} but w is N×{K2}")
+    out = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    sp = _dev(scale, "scale", torch.float32).data_ptr() if scale is not None else 0
+    hp = _dev(shift, "shift", torch.float32).data_ptr() if shift is not None else 0
+    _lib.check(_lib.load().frmap_linear_f32(x.data_ptr(), w.data_ptr(), sp, hp, out.data_ptr(), B, K, N, int(relu),
+                                            _stream()), "linear_f32")
+    return out
+
+
+def l2_normalize(x: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
+    x = _dev(x, "l2_normalize.x", torch.float32)
+    B, D = x.shape
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().frmap_l2_normalize_f32(x.data_ptr(), out.data_ptr(), B, D, float(eps), _stream()),
+               "l2_normalize")
+    return out
+
+
+def cast_to_f32(x: torch.Tensor) -> torch.Tensor:
+    x = _dev(x, "cast_to_f32.x")
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().frmap_cast_to_f32(x.data_ptr(), out.data_ptr(), x.numel(), dt_code(x.dtype), _stream()),
+               "cast_to_f32")
+    return out
+
+
+def cast_from_f32(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    x = _dev(x, "cast_from_f32.x", torch.float32)
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    _lib.check(_lib.load().frmap_cast_from_f32(x.data_ptr(), out.data_ptr(), x.numel(), dt_code(dtype), _stream()),
+               "cast_from_f32")
+    return out
+
+
+def _workspace(B: int, Cc: int, device) -> torch.Tensor:
+    n = _lib.load().frmap_head_workspace_bytes(B, Cc)
+    return torch.empty(((n + 15) // 16) * 2, dtype=torch.int64, device=device)
+
+
+def match_top1(emb: torch.Tensor, gallery: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """First arg-min over gallery rows of ``||e - g + 1e-6||_2`` and that distance (int32[B], fp32[B])."""
+    emb = _dev(emb, "match_top1.emb", torch.float32)
+    B, D = emb.shape
+    G = int(gallery.shape[0]) if gallery is not None else 0
+    gptr = 0
+    if G > 0:
+        gallery = _dev(gallery, "match_top1.gallery", torch.float32)
+        if gallery.shape[1] != D:
+            raise ValueError(f"match_top1: embedding dim {D} != gallery dim {gallery.shape[1]}")
+        gptr = gallery.data_ptr()
+    idx = torch.empty((B,), dtype=torch.int32, device=emb.device)
+    dist = torch.empty((B,), dtype=torch.float32, device=emb.device)
+    ws = _workspace(B, G, emb.device)
+    _lib.check(_lib.load().frmap_match_top1(emb.data_ptr(), gptr, idx.data_ptr(), dist.data_ptr(), ws.data_ptr(),
+                                            B, G, D, _stream()), "match_top1")
+    return idx, dist
+
+
+def cosine_logits(x: torch.Tensor, w: torch.Tensor, s: float = 1.0, want_logits: bool = True,
+                  want_argmax: bool = True):
+    x = _dev(x, "cosine_logits.x", torch.float32)
+    w = _dev(w, "cosine_logits.w", torch.float32)
+    B, D = x.shape
+    Cc = w.shape[0]
+    logits = torch.empty((B, Cc), dtype=torch.float32, device=x.device) if want_logits else None
+    arg = torch.empty((B,), dtype=torch.int32, device=x.device) if want_argmax else None
+    ws = _workspace(B, Cc, x.device)
+    _lib.check(_lib.load().frmap_cosine_logits(x.data_ptr(), w.data_ptr(), logits.data_ptr() if want_logits else 0,
+                                               arg.data_ptr() if want_argmax else 0, ws.data_ptr(), B, Cc, D,
+                                               float(s), _stream()), "cosine_logits")
+    return logits, arg
+
+
+def arcmargin_eval(x: torch.Tensor, w: torch.Tensor, label: torch.Tensor, s: float, m: float,
+                   easy_margin: bool = False, want_minmax: bool = False):
+    x = _dev(x, "arcmargin_eval.x", torch.float32)
+    w = _dev(w, "arcmargin_eval.w", torch.float32)
+    label = _dev(label, "arcmargin_eval.label", torch.int64)
+    B, D = x.shape
+    Cc = w.shape[0]
+    if label.numel() != B:
+        raise ValueError("arcmargin_eval: one label per row required")
+    out = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+    mm = torch.empty((2,), dtype=torch.float32, device=x.device) if want_minmax else None
+    ws = _workspace(B, Cc, x.device)
+    _lib.check(_lib.load().frmap_arcmargin_eval(x.data_ptr(), w.data_ptr(), label.data_ptr(), out.data_ptr(),
+                                                mm.data_ptr() if want_minmax else 0, ws.data_ptr(), B, Cc, D,
+                                                float(s), float(m), int(easy_margin), _stream()), "arcmargin_eval")
+    return out, mm

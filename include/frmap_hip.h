@@ -1,0 +1,148 @@
+/*
+ * frmap_hip.h — C ABI of the MI355X (gfx950) embedding-extraction + gallery-matching kernels.
+ *
+ * The reference (henryhcooperr/FaceRecognition-MultiArchitecture-Pipeline) has no FFI / plugin
+ * boundary of its own: its hot path is stock torch.nn ops called from Python
+ * (src/face_models.py, src/app.py).  This header is the boundary a maintainer binds instead; each
+ * entry point names the reference lines whose arithmetic it replaces.  INTEGRATION.md shows the
+ * ctypes stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless it says "host"; the library never allocates,
+ *     frees or synchronises: outputs and scratch are caller-owned, launches are asynchronous on
+ *     `stream` (a hipStream_t passed as void*; NULL = the default stream);
+ *   - return value: 0 = launched, negative = rejected before any launch (frmap_last_error()
+ *     gives the text); nothing is thrown across the ABI;
+ *   - `dtype`: FRMAP_BF16 or FRMAP_F16 = storage + MFMA input type of activations / packed conv
+ *     weights (accumulation is always fp32); heads and matching are fp32 throughout;
+ *   - activations are NHWC ("channels last"), C a multiple of 32 for frmap_conv_igemm.
+ */
+#ifndef FRMAP_HIP_H
+#define FRMAP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FRMAP_BF16 0
+#define FRMAP_F16 1
+
+/* ABI version of this header (bumped on any signature change). */
+int frmap_abi_version(void);
+/* Text of the last rejected call on this thread ("" if none). Host pointer, do not free. */
+const char* frmap_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Input layout: fp32 NCHW B×3×H×W  ->  NHWC4 (3 channels + one zero channel) in `dtype`.
+ * Replaces the implicit layout the reference feeds nn.Conv2d with (src/testing.py:99-104,251).
+ * ------------------------------------------------------------------------------------------- */
+int frmap_pack_input_nchw_f32(const float* x_nchw, void* out_nhwc4, int B, int H, int W,
+                              int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Conv weight packing.  `w_oihw` = fp32 [Cout][Cin][KH][KW] with the BatchNorm scale already
+ * folded in (w * gamma/sqrt(var+eps)); output is the kernel's LDS-image order in `dtype`.
+ *   frmap_pack_conv_weight      : for frmap_conv_igemm      (Cin % 32 == 0, Cout % 64 == 0,
+ *                                 KH == KW in {1,3});  out elems = Cout*Cin*KH*KW
+ *   frmap_pack_conv_weight_c3   : for frmap_conv_small_cin  (Cin == 3);  out elems =
+ *                                 Cout * frmap_small_cin_kpad(KH, KW)
+ * ------------------------------------------------------------------------------------------- */
+int frmap_pack_conv_weight(const float* w_oihw, void* w_packed, int Cout, int Cin, int KH, int KW,
+                           int dtype, void* stream);
+int frmap_small_cin_kpad(int KH, int KW);
+int frmap_pack_conv_weight_c3(const float* w_oihw, void* w_packed, int Cout, int KH, int KW,
+                              int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * First-layer convolution on NHWC4 input (Cin = 3) + per-channel shift + optional ReLU.
+ *   ResNet/Siamese stem 7x7 s2 p3 -> 64   (torchvision resnet18.conv1/bn1/relu via
+ *                                          src/face_models.py:67,463,658; face_models.py:115-117)
+ *   BaselineNet conv1 3x3 s1 p1 -> 32     (src/face_models.py:21-22,38)
+ * Implicit GEMM on v_mfma_f32_16x16x32 with the K axis laid along (kw, c) of each kernel row.
+ * out: NHWC B×Ho×Wo×Cout in `dtype`.  Cout in {32, 64}.
+ * ------------------------------------------------------------------------------------------- */
+int frmap_conv_small_cin(const void* in_nhwc4, const void* w_packed, const float* shift, void* out,
+                         int B, int Hi, int Wi, int Cout, int KH, int KW, int stride, int pad,
+                         int relu, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution, NHWC, MFMA 16x16x32 (bf16 / f16), fused epilogue
+ *     out = [relu]( conv(in, w) + shift[cout] [+ residual] )
+ * Covers: every 3x3 (s1/s2, p1) and 1x1 (s1/s2, p0) convolution + folded BatchNorm (+ReLU)
+ * (+ residual add) of the ResNet-18 BasicBlocks behind src/face_models.py:67,463,658, of
+ * BaselineNet conv2/conv3 (src/face_models.py:23-26,39-40), of SiameseNet (src/face_models.py:
+ * 121-141), and — as a 1x1 "conv" over H=W=1 — the wide Linear(+BatchNorm1d)(+ReLU) layers
+ * (src/face_models.py:148-155, 629-632).
+ *   in       : B×Hi×Wi×Cin   (dtype)
+ *   w_packed : from frmap_pack_conv_weight
+ *   shift    : fp32 [Cout]   (beta - mean*scale [+ bias*scale])
+ *   residual : B×Ho×Wo×Cout (dtype) or NULL
+ *   out      : B×Ho×Wo×Cout (dtype),  Ho = (Hi + 2*pad - K)/stride + 1
+ * ------------------------------------------------------------------------------------------- */
+int frmap_conv_igemm(const void* in, const void* w_packed, const float* shift, const void* residual,
+                     void* out, int B, int Hi, int Wi, int Cin, int Cout, int K, int stride, int pad,
+                     int relu, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pools (NHWC, `dtype`).
+ *   frmap_maxpool        : nn.MaxPool2d(k, s, p)  — (3,2,1) ResNet stem; (2,2,0) BaselineNet /
+ *                          SiameseNet (src/face_models.py:27,118,127,136)
+ *   frmap_avgpool_global : AdaptiveAvgPool2d(1) -> fp32 B×C (src/face_models.py:30,43; resnet
+ *                          avgpool)
+ *   frmap_avgpool_adaptive: AdaptiveAvgPool2d((OH,OW)) -> `dtype` B×OH×OW×C
+ *                          (src/face_models.py:142), windows [floor(i*H/OH), ceil((i+1)*H/OH))
+ * ------------------------------------------------------------------------------------------- */
+int frmap_maxpool(const void* in, void* out, int B, int H, int W, int C, int k, int stride, int pad,
+                  int dtype, void* stream);
+int frmap_avgpool_global(const void* in, float* out_f32, int B, int HW, int C, int dtype, void* stream);
+int frmap_avgpool_adaptive(const void* in, void* out, int B, int H, int W, int C, int OH, int OW,
+                           int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * fp32 heads.
+ *   frmap_linear_f32 : out[b][n] = [relu]( sum_k x[b][k]*w[n][k] * scale[n] + shift[n] )
+ *                      (scale/shift may be NULL = 1/0).  nn.Linear (+ folded BatchNorm1d):
+ *                      src/face_models.py:32-33,46-48; :75; :467-468,516-517; :488,580; :678
+ *   frmap_l2_normalize_f32 : F.normalize(x, p=2, dim=1, eps) = x / max(||x||, eps)
+ *                      (src/face_models.py:179,525,590)
+ *   frmap_cast_to_f32 / frmap_cast_from_f32 : dtype <-> fp32 element casts for head glue
+ * ------------------------------------------------------------------------------------------- */
+int frmap_linear_f32(const float* x, const float* w, const float* scale, const float* shift,
+                     float* out, int B, int K, int N, int relu, void* stream);
+int frmap_l2_normalize_f32(const float* x, float* out, int B, int D, float eps, void* stream);
+int frmap_cast_to_f32(const void* in, float* out, size_t n, int dtype, void* stream);
+int frmap_cast_from_f32(const float* in, void* out, size_t n, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Gallery matching (fp32, exact-f32 MFMA).
+ *   frmap_match_top1 : for each probe row e (B×D) the FIRST index minimising
+ *                      || e - g_i + 1e-6 ||_2 over gallery rows g (G×D) and that distance —
+ *                      the batched form of compare_faces' loop (src/app.py:58-63; F.pairwise_distance
+ *                      eps semantics).  idx_out int32[B], dist_out fp32[B].  G == 0 -> idx -1,
+ *                      dist +inf.
+ *   frmap_cosine_logits : logits[b][c] = s * <x_b/||x_b||, w_c/||w_c||>  and (optionally)
+ *                      argmax_out[b] — class-centre match (src/hyperparameter_tuning.py:1038-1046,
+ *                      src/face_models.py:889-893).  logits_out may be NULL.
+ *   frmap_arcmargin_eval : ArcMarginProduct.forward in eval mode (src/face_models.py:351-429):
+ *                      clamp(cos) -> acos -> target column cos(min(pi-1e-4, theta+m)) (or the
+ *                      easy-margin rule) -> * min(s,24) -> NaN/Inf -> 0.  label: int64[B].
+ *                      minmax_out (optional) fp32[2] receives max/min raw cosine (:358-360).
+ * ------------------------------------------------------------------------------------------- */
+/* Scratch each of the three calls below needs (device, caller-owned, >= this many bytes, 16-byte
+ * aligned); C = G for frmap_match_top1. */
+size_t frmap_head_workspace_bytes(int B, int C);
+int frmap_match_top1(const float* emb, const float* gallery, int32_t* idx_out, float* dist_out,
+                     void* workspace, int B, int G, int D, void* stream);
+int frmap_cosine_logits(const float* x, const float* w, float* logits_out, int32_t* argmax_out,
+                        void* workspace, int B, int C, int D, float s, void* stream);
+int frmap_arcmargin_eval(const float* x, const float* w, const int64_t* label, float* logits_out,
+                         float* minmax_out, void* workspace, int B, int C, int D, float s, float m,
+                         int easy_margin, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRMAP_HIP_H */
