@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Headline benchmark: faces/s for 224×224 embed + match (BASELINE.json), MI355X.
+
+A "step" = one pass of the hot path over one batch of synthetic faces already resident in HBM:
+fp32 NCHW batch → ResNet-18 embedding (HIP kernels, bf16 MFMA) → L2-normalise → top-1 match against
+a 36-ID gallery (configs[1]: "ResNet18 ('cnn') bf16 embed+match, batch 256, 1×MI355X, 36-ID
+gallery").  With N GPUs every rank runs the same per-GPU batch (weak scaling: faces shard
+embarrassingly) and one RCCL all-gather collates the (id, distance) pairs each step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     — the dominant kernel (conv_igemm_kernel<BF16,256,3,1>: the 3×3 stride-1 implicit-GEMM
+                 convolutions, 13 launches per step): algorithmic FLOPs per launch ÷ its average launch
+                 duration, measured with HIP events on the launch stream in a separate instrumented
+                 pass after the timed region; peak = 2.5 PFLOP/s dense bf16 MFMA.
+  cpu_baseline — the CPU oracle (oracle/face_oracle.py, fp32 PyTorch restatement of the reference's
+                 forward) timed on this box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/fp16, MI355X_MICROARCH.md
+DOMINANT = "conv_igemm_kernel<BF16,256,3,1>"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="faces per GPU per step")
+    ap.add_argument("--gallery", type=int, default=36)
+    ap.add_argument("--model", default="cnn", choices=["cnn", "arcface", "baseline", "siamese"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import frmap_amd
+    from frmap_amd import dist as fdist
+    from frmap_amd import ops, synth
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    B, G = args.batch, args.gallery
+    model = frmap_amd.get_model(args.model, 36)
+    sd = synth.synth_state_dict(synth.shapes_of(model), 1002)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval().set_compute_dtype(dtype)
+    gallery = frmap_amd.Gallery([f"id{i}" for i in range(G)], synth.unit_rows(3002, G, 512 if args.model != "siamese" else 256), dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(2002 + rank)
+    x = torch.randn((B, 3, 224, 224), device=dev, dtype=torch.float32, generator=gen)  # resident in HBM
+    need_norm = args.model in ("cnn", "baseline")
+    total = B * world
+
+    def step():
+        ids, d = frmap_amd.embed_and_match(model, x, gallery, 1.0, normalize=need_norm)
+        if world > 1:
+            ids, d = fdist.gather_results(ids, d, total)
+        return ids, d
+
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 1) if args.warmup > 0 else 0):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    faces_per_s = total * args.steps / elapsed
+
+    # ---------------- roofline of the dominant kernel (instrumented pass, not part of `value`) ----
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        records = []
+        orig = ops.conv_igemm
+
+        def timed(x_, wpk, shift, Cout, k, stride, pad, relu, residual=None):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = orig(x_, wpk, shift, Cout, k, stride, pad, relu, residual)
+            e1.record()
+            Bn, H, W, Cin = x_.shape
+            records.append((e0, e1, k, stride, 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * Cout * Cin * k * k))
+            return y
+
+        import frmap_amd.face_models as fm
+        fm.ops.conv_igemm = timed
+        try:
+            with torch.no_grad():
+                for _ in range(5):
+                    step()
+            torch.cuda.synchronize()
+        finally:
+            fm.ops.conv_igemm = orig
+        dom = [(e0.elapsed_time(e1) * 1e-3, fl) for e0, e1, k, s, fl in records if k == 3 and s == 1]
+        allc = [(e0.elapsed_time(e1) * 1e-3, fl) for e0, e1, k, s, fl in records]
+        if dom:
+            tsum, fsum = sum(t for t, _ in dom), sum(f for _, f in dom)
+            achieved = fsum / tsum / 1e12
+            roofline = {"bound": "mfma", "kernel": DOMINANT if dtype == torch.bfloat16 else DOMINANT.replace("BF16", "F16"),
+                        "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                        "launches_per_step": len(dom) // 5, "avg_launch_us": round(tsum / len(dom) * 1e6, 2),
+                        "flop_per_launch": fsum / len(dom),
+                        "all_conv_igemm_tflops": round(sum(f for _, f in allc) / sum(t for t, _ in allc) / 1e12, 2),
+                        "conv_igemm_ms_per_step": round(sum(t for t, _ in allc) / 5 * 1e3, 3)}
+
+    # ---------------- CPU baseline: the oracle on the host cores (bounded sample) -----------------
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import face_oracle as fo
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        nb = 64
+        xc = x[:nb].cpu()
+        gal = gallery.matrix.cpu()
+        emb_fn = {"cnn": fo.cnn_embedding, "arcface": fo.arcface_embedding, "baseline": fo.baseline_embedding,
+                  "siamese": fo.siamese_forward_one}[args.model]
+        best = float("inf")
+        with torch.no_grad():
+            for rep in range(4):
+                c0 = time.perf_counter()
+                e = emb_fn(sd, xc)
+                e = torch.nn.functional.normalize(e, dim=1) if need_norm else e
+                fo.match_top1(e, gal)
+                c1 = time.perf_counter()
+                if rep > 0:
+                    best = min(best, c1 - c0)
+        cpu_baseline = {"value": round(nb / best, 1), "unit": "faces/s", "cores": cores, "kind": "port",
+                        "sample": f"{nb} faces (same synthetic batch), fp32 torch-CPU oracle forward + L2-normalise + "
+                                  f"{G}-ID match, best of 3 after 1 warm-up"}
+
+    if rank == 0:
+        line = {
+            "metric": "faces/sec (224x224 embed+match)", "value": round(faces_per_s, 1), "unit": "faces/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"ResNet18 ('{args.model}') embed + L2-normalise + top-1 match, batch {B}/GPU, "
+                                   f"{G}-ID gallery, 224x224x3 fp32 NCHW inputs resident in HBM, random-init weights",
+                       "global_batch": total, "parallelism": f"dp{world} (faces sharded, 1 all-gather of 8 B/face)"},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,178 @@
+"""GPU: every HIP kernel, called through the C ABI, against a plain PyTorch fp32 reference of the
+same op computed on the CPU from the SAME rounded operands (so the only differences are fp32
+accumulation order and the final rounding to the storage dtype)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from frmap_amd import ops, synth  # noqa: E402
+
+DEV = "cuda"
+DTYPES = [torch.float16, torch.bfloat16]
+
+
+def _nhwc(x_nchw):
+    return x_nchw.permute(0, 2, 3, 1).contiguous()
+
+
+def _tol(dtype):
+    # one rounding of the output to the storage dtype + fp32 accumulation noise
+    return (2e-3, 2e-3) if dtype == torch.float16 else (1.6e-2, 1.6e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,res,relu", [
+    (2, 56, 56, 64, 64, 3, 1, True, True),       # resnet layer1
+    (3, 56, 56, 64, 128, 3, 2, False, True),     # layer2.0.conv1 (stride 2)
+    (3, 56, 56, 64, 128, 1, 2, False, False),    # layer2.0.downsample
+    (5, 28, 28, 128, 128, 3, 1, True, True),
+    (7, 14, 14, 256, 256, 3, 1, False, False),
+    (9, 7, 7, 512, 512, 3, 1, True, True),       # many images per tile, ragged tail (441 px)
+    (2, 14, 14, 256, 512, 3, 2, False, True),
+    (1, 112, 112, 32, 64, 3, 1, False, True),    # BaselineNet conv2
+    (2, 10, 6, 32, 64, 3, 1, False, False),      # odd small geometry
+    (37, 1, 1, 1024, 512, 1, 1, False, True),    # Linear as 1x1
+])
+def test_conv_igemm(dtype, B, H, W, Cin, Cout, k, s, res, relu):
+    pad = 1 if k == 3 else 0
+    x = synth.randn(11, (B, Cin, H, W), "x").to(dtype)
+    w = (synth.randn(12, (Cout, Cin, k, k), "w") * math.sqrt(2.0 / (Cin * k * k))).to(dtype)
+    shift = synth.randn(13, (Cout,), "b") * 0.1
+    y_ref = F.conv2d(x.float(), w.float(), None, stride=s, padding=pad) + shift.view(1, -1, 1, 1)
+    r = None
+    if res:
+        r = synth.randn(14, tuple(y_ref.shape), "r").to(dtype)
+        y_ref = y_ref + r.float()
+    if relu:
+        y_ref = F.relu(y_ref)
+    wpk = ops.pack_conv_weight(w.float().to(DEV), dtype)
+    y = ops.conv_igemm(_nhwc(x).to(DEV), wpk, shift.to(DEV), Cout, k, s, pad, relu,
+                       _nhwc(r).to(DEV) if r is not None else None)
+    y = y.float().cpu().permute(0, 3, 1, 2)
+    atol, rtol = _tol(dtype)
+    assert y.shape == y_ref.shape
+    assert torch.allclose(y, y_ref, atol=atol, rtol=rtol), (y - y_ref).abs().max()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,Cout,k,s,pad", [(2, 224, 224, 64, 7, 2, 3), (3, 64, 48, 64, 7, 2, 3),
+                                                 (2, 224, 224, 32, 3, 1, 1), (3, 20, 12, 32, 3, 1, 1)])
+def test_conv_small_cin(dtype, B, H, W, Cout, k, s, pad):
+    x = synth.randn(21, (B, 3, H, W), "x")
+    w = (synth.randn(22, (Cout, 3, k, k), "w") * math.sqrt(2.0 / (3 * k * k))).to(dtype)
+    shift = synth.randn(23, (Cout,), "b") * 0.1
+    x4 = ops.pack_input(x.to(DEV), dtype)
+    # pack_input itself: NHWC4 with a zero 4th channel, rounded to dtype
+    x4c = x4.float().cpu()
+    assert torch.equal(x4c[..., :3], _nhwc(x).to(dtype).float()) and float(x4c[..., 3].abs().max()) == 0.0
+    y_ref = F.relu(F.conv2d(x.to(dtype).float(), w.float(), None, stride=s, padding=pad) + shift.view(1, -1, 1, 1))
+    y = ops.conv_small_cin(x4, ops.pack_conv_weight_c3(w.float().to(DEV), dtype), shift.to(DEV), Cout, k, s, pad, True)
+    y = y.float().cpu().permute(0, 3, 1, 2)
+    atol, rtol = _tol(dtype)
+    assert torch.allclose(y, y_ref, atol=atol, rtol=rtol), (y - y_ref).abs().max()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pools(dtype):
+    x = synth.randn(31, (3, 64, 30, 22), "x").to(dtype)
+    xd = _nhwc(x).to(DEV)
+    for k, s, p in ((3, 2, 1), (2, 2, 0)):
+        y = ops.maxpool(xd, k, s, p).float().cpu().permute(0, 3, 1, 2)
+        assert torch.equal(y, F.max_pool2d(x.float(), k, s, p))          # exact: max of representable values
+    g = ops.avgpool_global(xd).cpu()
+    assert torch.allclose(g, x.float().mean(dim=(2, 3)), atol=1e-5)
+    x2 = synth.randn(32, (2, 512, 14, 14), "x").to(dtype)
+    a = ops.avgpool_adaptive(_nhwc(x2).to(DEV), 6, 6).float().cpu().permute(0, 3, 1, 2)
+    atol, rtol = _tol(dtype)
+    assert torch.allclose(a, F.adaptive_avg_pool2d(x2.float(), (6, 6)), atol=atol, rtol=rtol)
+    for dt in (dtype,):
+        t = synth.randn(33, (1000,), "c")
+        assert torch.equal(ops.cast_from_f32(t.to(DEV), dt).cpu(), t.to(dt))
+        assert torch.equal(ops.cast_to_f32(t.to(dt).to(DEV)).cpu(), t.to(dt).float())
+
+
+@pytest.mark.parametrize("B,K,N,relu", [(1, 512, 36, False), (70, 128, 512, True), (256, 512, 512, False), (3, 512, 1000, False)])
+def test_linear_f32_and_normalize(B, K, N, relu):
+    x = synth.randn(41, (B, K), "x")
+    w = synth.randn(42, (N, K), "w") / math.sqrt(K)
+    sc = synth.randn(43, (N,), "s").abs() + 0.5
+    sh = synth.randn(44, (N,), "h")
+    ref = (x.double() @ w.double().t()) * sc.double() + sh.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    y = ops.linear_f32(x.to(DEV), w.to(DEV), sc.to(DEV), sh.to(DEV), relu).cpu()
+    assert torch.allclose(y.double(), ref, atol=2e-5, rtol=2e-5), (y.double() - ref).abs().max()
+    y2 = ops.linear_f32(x.to(DEV), w.to(DEV)).cpu()
+    assert torch.allclose(y2.double(), x.double() @ w.double().t(), atol=2e-5, rtol=2e-5)
+    n = ops.l2_normalize(x.to(DEV), 1e-12).cpu()
+    assert torch.allclose(n, F.normalize(x, p=2, dim=1, eps=1e-12), atol=1e-6)
+    z = torch.zeros(2, K)
+    assert torch.equal(ops.l2_normalize(z.to(DEV), 1e-12).cpu(), z)       # x / max(0, eps) = 0, no NaN
+
+
+def _ref_match(e, g):
+    d = torch.sqrt(((e[:, None, :].double() - g[None].double() + 1e-6) ** 2).sum(-1))
+    dist, idx = d.min(1)
+    return idx.int(), dist.float(), d
+
+
+@pytest.mark.parametrize("B,G,D", [(1, 7, 512), (16, 36, 512), (100, 1000, 512), (257, 1300, 512), (5, 129, 256)])
+def test_match_top1(B, G, D):
+    gal = synth.unit_rows(51, G, D)
+    pr = synth.unit_rows(52, B, D, tag="p")
+    pr[0] = gal[G // 2]                     # exact hit: distance sqrt(D)*1e-6
+    idx, dist = ops.match_top1(pr.to(DEV), gal.to(DEV))
+    ridx, rdist, dm = _ref_match(pr, gal)
+    idx, dist = idx.cpu(), dist.cpu()
+    top2 = dm.topk(2, dim=1, largest=False).values if G > 1 else None
+    for b in range(B):
+        if idx[b] != ridx[b]:               # only a sub-ulp near-tie may differ
+            assert top2 is not None and float(top2[b, 1] - top2[b, 0]) < 1e-6, (b, idx[b], ridx[b])
+    assert int(idx[0]) == G // 2 and abs(float(dist[0]) - math.sqrt(D) * 1e-6) < 2e-6
+    assert torch.allclose(dist, rdist, atol=2e-6, rtol=1e-5)
+
+
+def test_match_top1_edge_cases():
+    D = 512
+    pr = synth.unit_rows(61, 3, D)
+    idx, dist = ops.match_top1(pr.to(DEV), torch.zeros((0, D), device=DEV))
+    assert idx.cpu().tolist() == [-1, -1, -1] and torch.isinf(dist).all()      # empty gallery
+    gal = synth.unit_rows(62, 9, D)
+    gal[6] = gal[2]                                                                # duplicate rows: FIRST minimum wins
+    idx, _ = ops.match_top1(gal[6:7].to(DEV), gal.to(DEV))
+    assert int(idx[0]) == 2
+
+
+def test_cosine_logits_and_arcmargin(gold_dir):
+    import os
+    z = np.load(os.path.join(gold_dir, "arcmargin.npz"))
+    w = synth.randn(1003, (1000, 512), tag="arcmargin.weight")
+    x = synth.randn(2003, (32, 512), tag="arcmargin.x")
+    lab = torch.from_numpy(z["labels"]).long()
+    for name, kw in (("s30_m05", dict(s=30.0, m=0.5)), ("s32_m05", dict(s=32.0, m=0.5)),
+                     ("s16_m03_easy", dict(s=16.0, m=0.3, easy_margin=True))):
+        out, mm = ops.arcmargin_eval(x.to(DEV), w.to(DEV), lab.to(DEV), kw["s"], kw["m"], kw.get("easy_margin", False),
+                                     want_minmax=True)
+        ref = torch.from_numpy(z[name])
+        assert torch.allclose(out.cpu(), ref, atol=2e-4), (name, (out.cpu() - ref).abs().max())
+    cos = F.linear(F.normalize(x), F.normalize(w))
+    assert abs(float(mm[0]) - float(cos.max())) < 1e-5 and abs(float(mm[1]) - float(cos.min())) < 1e-5
+    logits, arg = ops.cosine_logits(x.to(DEV), w.to(DEV), s=32.0)
+    assert torch.allclose(logits.cpu(), cos * 32.0, atol=1e-4)
+    assert arg.cpu().tolist() == (cos * 32.0).argmax(1).tolist()
+    _, arg2 = ops.cosine_logits(x.to(DEV), w.to(DEV), s=1.0, want_logits=False)
+    assert arg2.cpu().tolist() == arg.cpu().tolist()
+
+
+def test_rejections_do_not_launch():
+    with pytest.raises(ValueError):
+        ops.conv_igemm(torch.zeros(1, 8, 8, 48, device=DEV, dtype=torch.float16),
+                       torch.zeros(48 * 64 * 9, device=DEV, dtype=torch.float16), torch.zeros(64, device=DEV),
+                       64, 3, 1, 1, True)            # Cin not a multiple of 32
+    with pytest.raises(TypeError):
+        ops.pack_input(torch.zeros(1, 3, 8, 8, device=DEV), torch.float32)
