@@ -143,7 +143,13 @@ def main():
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import face_oracle as fo
-        cores = os.cpu_count() or 1
+        # the GPU box exposes 256 logical CPUs but a 1-GPU job owns a 16-core share; more threads
+        # than that only oversubscribe the quota (measured: 256 threads -> 3.8 faces/s)
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        cores = max(1, min(avail, int(os.environ.get("FRMAP_CPU_THREADS", "16"))))
         torch.set_num_threads(cores)
         nb = 64
         xc = x[:nb].cpu()
