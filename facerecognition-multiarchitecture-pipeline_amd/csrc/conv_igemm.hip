@@ -21,6 +21,7 @@
 //   Weights are pre-packed on the device (pack_weight.hip) in exactly the LDS image order, so the
 //            slab is a straight 36 KB copy done with global_load_lds_dwordx4 (no VGPRs).
 #include "frmap_common.h"
+#include <stdlib.h>
 
 struct ConvParams {
   const void* in;
@@ -35,6 +36,7 @@ struct ConvParams {
   int nchunks;
   int halo_bytes;
   int nblocks;
+  int dbg;  // timing ablations only (FRMAP_CONV_DEBUG): 1 = stage chunk 0 only, 2 = skip the MFMA loop
 };
 
 template <int SWZ>
@@ -130,6 +132,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 
   for (int chunk = 0; chunk < p.nchunks; ++chunk) {
     if (chunk > 0) __syncthreads();  // everyone is done reading the previous chunk's LDS images
+    if (!(p.dbg == 1 && chunk > 0)) {
     // ---- weights: straight LDS-DMA copy of the pre-packed slab -------------------------------
     {
       const char* wsrc = (const char*)p.wpk + ((size_t)(nt * p.nchunks + chunk) * TAPS) * 4096 + tid * 16;
@@ -181,20 +184,40 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
           if (dst[u] >= 0) *(u32x4_t*)(halo + dst[u]) = v[u];
       }
     }
+    }
     __syncthreads();  // (also drains the LDS-DMA: hipcc emits vmcnt(0) ahead of the barrier)
+    if (p.dbg == 2) continue;
 
     // ---- KS*KS k-steps of 32 channels out of LDS -----------------------------------------------
+    // Fragment reads run one tap ahead of the MFMAs (two register sets); sched_group_barrier pins
+    // the interleave "1 ds_read_b128 : 2 MFMA" so LDS latency hides under the matrix pipe.
+    {
+      vec8 wf[2][NI], pf[2][MI];
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
-      vec8 wf[NI], pf[MI];
+      for (int ni = 0; ni < NI; ++ni) wf[0][ni] = *(const vec8*)(wl + ni * 1024 + woff);
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) wf[ni] = *(const vec8*)(wl + t * 4096 + ni * 1024 + woff);
+      for (int mi = 0; mi < MI; ++mi) pf[0][mi] = *(const vec8*)(halo + offs[mi][0]);
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) pf[mi] = *(const vec8*)(halo + offs[mi][t]);
+      for (int t = 0; t < TAPS; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        if (t + 1 < TAPS) {
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
+          for (int ni = 0; ni < NI; ++ni) wf[nxt][ni] = *(const vec8*)(wl + (t + 1) * 4096 + ni * 1024 + woff);
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = TT::mfma(wf[ni], pf[mi], acc[mi][ni]);
+          for (int mi = 0; mi < MI; ++mi) pf[nxt][mi] = *(const vec8*)(halo + offs[mi][t + 1]);
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = TT::mfma(wf[cur][ni], pf[cur][mi], acc[mi][ni]);
+        if (t + 1 < TAPS) {
+#pragma unroll
+          for (int i = 0; i < NI + MI; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                    // 1 DS read
+            __builtin_amdgcn_sched_group_barrier(0x008, (MI * NI) / (NI + MI), 0);  // then MFMAs
+          }
+        }
+      }
     }
   }
 
@@ -280,6 +303,11 @@ extern "C" int frmap_conv_igemm(const void* in, const void* w_packed, const floa
   p.M = (int)Mll; p.HoWo = Ho * Wo; p.Hp = Hi + 2 * pad; p.Wp = Wi + 2 * pad;
   p.magic_Wp = frmap_magic((uint32_t)p.Wp); p.magic_Hp = frmap_magic((uint32_t)p.Hp);
   p.nchunks = Cin / 32;
+  {
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("FRMAP_CONV_DEBUG"); dbg = e ? atoi(e) : 0; }
+    p.dbg = dbg;
+  }
   hipStream_t st = (hipStream_t)stream;
   const int wbytes = K * K * 4096;
   const int ntiles = Cout / 64;
