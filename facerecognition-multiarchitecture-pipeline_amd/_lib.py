@@ -29,6 +29,7 @@ PROTOTYPES = {
     "frmap_small_cin_kpad": (_i, [_i, _i]),
     "frmap_pack_conv_weight_c3": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "frmap_conv_small_cin": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "frmap_stem7x7_maxpool": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "frmap_conv_igemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "frmap_maxpool": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "frmap_avgpool_global": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

@@ -221,32 +221,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     }
   }
 
-  // ---- epilogue: + shift (+ residual) (ReLU) -> NHWC store, 4 channels (8 B) per lane ---------
-  typename TT::elem* outp = (typename TT::elem*)p.out;
-  const typename TT::elem* resp = (const typename TT::elem*)p.res;
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int co = (nt << 6) + ni * 16 + g * 4;
-    const f32x4_t sh = *(const f32x4_t*)(p.shift + co);
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int m = m0 + wave * (BM / 4) + mi * 16 + lr;
-      if (m < p.M) {
-        const size_t o = (size_t)m * p.Cout + co;
-        float v[4] = {acc[mi][ni][0] + sh[0], acc[mi][ni][1] + sh[1], acc[mi][ni][2] + sh[2],
-                      acc[mi][ni][3] + sh[3]};
-        if (resp) {
-          float r[4];
-          unpack4<TT>(*(const u32x2_t*)(resp + o), r);
-          v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
-        }
-        if (p.relu) {
-          v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-        }
-        *(u32x2_t*)(outp + o) = pack4<TT>(v[0], v[1], v[2], v[3]);
-      }
-    }
-  }
+  // ---- epilogue: + shift (+ residual) (ReLU) -> NHWC, whole-line 16-byte stores via an LDS transpose
+  __syncthreads();  // every wave is done reading the staged tiles; LDS is free for the transpose
+  conv_epilogue<TT, MI, NI>(acc, smem + wave * (16 * (NI * 64 + 16)), m0 + wave * (BM / 4), p.M, p.Cout, nt << 6,
+                            p.shift, (const typename TT::elem*)p.res, (typename TT::elem*)p.out, p.relu, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -274,6 +252,8 @@ static int launch(const ConvParams& p, int lds_bytes, hipStream_t st) {
     }
     attr_set = 160 * 1024;
   }
+  const int scratch = 4 * 16 * (4 * 64 + 16);  // epilogue transpose region (4 waves)
+  if (lds_bytes < scratch) lds_bytes = scratch;
   hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), lds_bytes, st, p);
   FRMAP_LAUNCH_CHECK();
   return 0;

@@ -149,24 +149,9 @@ __global__ __launch_bounds__(256, 2) void conv_small_cin_kernel(const SmallCinPa
       for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = TT::mfma(wf[ni], pf[mi], acc[mi][ni]);
   }
 
-  typename TT::elem* outp = (typename TT::elem*)p.out;
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int co = ni * 16 + g * 4;
-    const f32x4_t sh = *(const f32x4_t*)(p.shift + co);
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int m = m0 + wave * 64 + mi * 16 + lr;
-      if (m < p.M) {
-        float v[4] = {acc[mi][ni][0] + sh[0], acc[mi][ni][1] + sh[1], acc[mi][ni][2] + sh[2],
-                      acc[mi][ni][3] + sh[3]};
-        if (p.relu) {
-          v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-        }
-        *(u32x2_t*)(outp + (size_t)m * COUT + co) = pack4<TT>(v[0], v[1], v[2], v[3]);
-      }
-    }
-  }
+  __syncthreads();  // LDS tiles are dead: reuse them for the store transpose
+  conv_epilogue<TT, MI, NI>(acc, smem + wave * (16 * (NI * 64 + 16)), m0 + wave * 64, p.M, COUT, 0, p.shift,
+                            (const typename TT::elem*)nullptr, (typename TT::elem*)p.out, p.relu, lane);
 }
 
 static int small_rows_bound(int BM, int Ho, int Wo, int Hp, int stride, int KH) {
@@ -201,7 +186,10 @@ static int launch_small(SmallCinParams& p, hipStream_t st) {
     }
     attr = true;
   }
-  hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), (int)hb + wbytes, st, p);
+  int lds = (int)hb + wbytes;
+  const int scratch = 4 * 16 * (NI * 64 + 16);  // epilogue transpose region (4 waves)
+  if (lds < scratch) lds = scratch;
+  hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), lds, st, p);
   FRMAP_LAUNCH_CHECK();
   return 0;
 }

@@ -64,6 +64,67 @@ __device__ __forceinline__ u32x4_t pack8(const float* f) {
   return r;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Shared conv epilogue.  After the K loop a lane holds, per 16x16 MFMA tile (mi, ni), 4 consecutive
+// output channels (ni*16 + g*4 ..+3) of ONE pixel (mi*16 + lr).  Storing that directly is 8 bytes
+// per lane scattered over 16 pixel rows per instruction (32-byte fragments of 128-byte lines).
+// Instead each wave transposes 16 pixels at a time through its own LDS scratch (fp32, row pitch
+// NI*64+16 bytes) so that 8 consecutive lanes own one pixel's channel run and every global access
+// (residual load, output store) is 16 bytes per lane and a whole line per 8 (or 4) lanes.
+//   v = acc + shift[c] (+ residual) ; relu ; round once to the storage dtype.
+// Caller guarantees: all waves are past their last read of the LDS tiles (a barrier), `scratch`
+// is this wave's private 16*(NI*64+16)-byte region, 16-byte aligned.
+// ------------------------------------------------------------------------------------------------
+template <typename TT, int MI, int NI>
+__device__ __forceinline__ void conv_epilogue(const f32x4_t (&acc)[MI][NI], char* scratch, int m_wave0, int M,
+                                              int Cout, int co0, const float* __restrict__ shift,
+                                              const typename TT::elem* __restrict__ res,
+                                              typename TT::elem* __restrict__ out, int relu, int lane) {
+  constexpr int PITCH = NI * 64 + 16;      // bytes per pixel row in scratch
+  constexpr int PARTS = NI * 2;            // 8-channel runs per pixel
+  constexpr int PER_LANE = PARTS / 4;      // (16 px * PARTS) / 64 lanes
+  const int lr = lane & 15, g = lane >> 4;
+  // this lane's channel run is the same in every pass
+  float sh[PER_LANE][8];
+  int part[PER_LANE], prow[PER_LANE];
+#pragma unroll
+  for (int j = 0; j < PER_LANE; ++j) {
+    const int idx = j * 64 + lane;
+    prow[j] = idx / PARTS;
+    part[j] = idx % PARTS;
+    const f32x4_t s0 = *(const f32x4_t*)(shift + co0 + part[j] * 8), s1 = *(const f32x4_t*)(shift + co0 + part[j] * 8 + 4);
+    sh[j][0] = s0[0]; sh[j][1] = s0[1]; sh[j][2] = s0[2]; sh[j][3] = s0[3];
+    sh[j][4] = s1[0]; sh[j][5] = s1[1]; sh[j][6] = s1[2]; sh[j][7] = s1[3];
+  }
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) *(f32x4_t*)(scratch + lr * PITCH + ni * 64 + g * 16) = acc[mi][ni];
+#pragma unroll
+    for (int j = 0; j < PER_LANE; ++j) {
+      const f32x4_t a = *(const f32x4_t*)(scratch + prow[j] * PITCH + part[j] * 32);
+      const f32x4_t b = *(const f32x4_t*)(scratch + prow[j] * PITCH + part[j] * 32 + 16);
+      const int m = m_wave0 + mi * 16 + prow[j];
+      if (m < M) {
+        const size_t o = (size_t)m * Cout + co0 + part[j] * 8;
+        float v[8] = {a[0] + sh[j][0], a[1] + sh[j][1], a[2] + sh[j][2], a[3] + sh[j][3],
+                      b[0] + sh[j][4], b[1] + sh[j][5], b[2] + sh[j][6], b[3] + sh[j][7]};
+        if (res) {
+          float r[8];
+          unpack8<TT>(*(const u32x4_t*)(res + o), r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += r[e];
+        }
+        if (relu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        *(u32x4_t*)(out + o) = pack8<TT>(v);
+      }
+    }
+  }
+}
+
 // exact floor(n / d) for n, d < 65536 with magic = ceil(2^32 / d)
 __host__ __device__ inline uint32_t frmap_magic(uint32_t d) {
   return (uint32_t)(((1ull << 32) + d - 1) / d);

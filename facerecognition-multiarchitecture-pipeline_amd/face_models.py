@@ -203,9 +203,10 @@ class _TrunkPlan:
 
     def features(self, x: torch.Tensor) -> torch.Tensor:
         """fp32 NCHW → NHWC B×7×7×512 (for 224² input) in the compute dtype."""
-        x = ops.pack_input(x, self.dtype)
-        x = self.stem(x, relu=True)
-        x = ops.maxpool(x, 3, 2, 1)
+        if ops.stem_pool_dims(x.shape[2], x.shape[3])[1] <= 56:
+            x = ops.stem7x7_maxpool(x, self.stem.wpk, self.stem.shift, self.dtype)   # fused stem, one kernel
+        else:  # wider than the fused kernel's 8 column strips
+            x = ops.maxpool(self.stem(ops.pack_input(x, self.dtype), relu=True), 3, 2, 1)
         for c1, c2, ds in self.blocks:
             idn = ds(x, relu=False) if ds is not None else x
             x = c2(c1(x, relu=True), relu=True, residual=idn)

@@ -85,6 +85,25 @@ def conv_small_cin(x4: torch.Tensor, wpk: torch.Tensor, shift: torch.Tensor, Cou
     return out
 
 
+def stem_pool_dims(H: int, W: int):
+    Hc, Wc = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    return (Hc + 2 - 3) // 2 + 1, (Wc + 2 - 3) // 2 + 1
+
+
+def stem7x7_maxpool(x: torch.Tensor, wpk: torch.Tensor, shift: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """fp32 NCHW -> conv7x7 s2 + shift + ReLU -> maxpool 3x3 s2 p1 -> NHWC B×Hq×Wq×64 (``dtype``)."""
+    x = _dev(x, "stem7x7_maxpool.x", torch.float32)
+    B, C, H, W = x.shape
+    if C != 3:
+        raise ValueError("stem7x7_maxpool: expected 3 input channels")
+    Hq, Wq = stem_pool_dims(H, W)
+    out = torch.empty((B, Hq, Wq, 64), dtype=dtype, device=x.device)
+    _lib.check(_lib.load().frmap_stem7x7_maxpool(x.data_ptr(), _dev(wpk, "wpk", dtype).data_ptr(),
+                                                 _dev(shift, "shift", torch.float32).data_ptr(), out.data_ptr(),
+                                                 B, H, W, dt_code(dtype), _stream()), "stem7x7_maxpool")
+    return out
+
+
 def conv_igemm(x: torch.Tensor, wpk: torch.Tensor, shift: torch.Tensor, Cout: int, k: int, stride: int, pad: int,
                relu: bool, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     x = _dev(x, "conv_igemm.x")

@@ -69,6 +69,16 @@ int frmap_conv_small_cin(const void* in_nhwc4, const void* w_packed, const float
                          int relu, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused ResNet stem: fp32 NCHW B×3×Hi×Wi -> conv 7x7 s2 p3 (3->64) + shift + ReLU -> maxpool 3x3 s2 p1
+ * -> NHWC B×Hq×Wq×64 in `dtype`, one kernel (the 64×112×112 conv map never reaches HBM).
+ * Replaces conv1/bn1/relu/maxpool of torchvision resnet18 (src/face_models.py:67,463,658) plus the
+ * input layout cast.  w_packed_c3: from frmap_pack_conv_weight_c3(…, 64, 7, 7).  Needs Wi <= ~224
+ * (pooled width <= 56); wider inputs use frmap_pack_input + frmap_conv_small_cin + frmap_maxpool.
+ * ------------------------------------------------------------------------------------------- */
+int frmap_stem7x7_maxpool(const float* x_nchw, const void* w_packed_c3, const float* shift, void* out,
+                          int B, int Hi, int Wi, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution, NHWC, MFMA 16x16x32 (bf16 / f16), fused epilogue
  *     out = [relu]( conv(in, w) + shift[cout] [+ residual] )
  * Covers: every 3x3 (s1/s2, p1) and 1x1 (s1/s2, p0) convolution + folded BatchNorm (+ReLU)
