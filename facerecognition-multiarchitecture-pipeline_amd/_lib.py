@@ -13,7 +13,7 @@ import threading
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libfrmap_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lock = threading.Lock()
 _lib = None
@@ -39,7 +39,7 @@ PROTOTYPES = {
     "frmap_cast_to_f32": (_i, [_vp, _vp, _sz, _i, _vp]),
     "frmap_cast_from_f32": (_i, [_vp, _vp, _sz, _i, _vp]),
     "frmap_head_workspace_bytes": (_sz, [_i, _i]),
-    "frmap_match_top1": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "frmap_match_top1": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "frmap_cosine_logits": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "frmap_arcmargin_eval": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
 }

@@ -238,12 +238,13 @@ __global__ void fill_u64_kernel(unsigned long long* p, int n, unsigned long long
 // exact distance of the winner, the way F.pairwise_distance forms it: ||(a - g) + eps||_2 in fp32
 __global__ void match_finalize_kernel(const float* __restrict__ emb, const float* __restrict__ gal,
                                       const unsigned long long* __restrict__ keys, int32_t* __restrict__ idx_out,
-                                      float* __restrict__ dist_out, int B, int G, int D) {
+                                      float* __restrict__ dist_out, int32_t* __restrict__ id_thr_out, float thresh,
+                                      int B, int G, int D) {
   const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (b >= B) return;
   const unsigned long long key = keys[b];
   if (G <= 0 || key == ~0ull) {
-    if (lane == 0) { idx_out[b] = -1; dist_out[b] = INFINITY; }
+    if (lane == 0) { idx_out[b] = -1; dist_out[b] = INFINITY; if (id_thr_out) id_thr_out[b] = -1; }
     return;
   }
   const int g = (int)(key & 0xFFFFFFFFull);
@@ -254,7 +255,39 @@ __global__ void match_finalize_kernel(const float* __restrict__ emb, const float
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
-  if (lane == 0) { idx_out[b] = g; dist_out[b] = sqrtf(s2); }
+  if (lane == 0) {
+    const float d = sqrtf(s2);
+    idx_out[b] = g; dist_out[b] = d;
+    if (id_thr_out) id_thr_out[b] = d <= thresh ? g : -1;
+  }
+}
+
+// Small galleries (the demo's handful of enrolled faces, the 36-ID benchmark gallery): one wave per
+// probe walks the gallery directly with the exact F.pairwise_distance arithmetic — no GEMM
+// expansion, no atomics, one launch.  lane owns dims lane, lane+64, ...
+__global__ void match_small_kernel(const float* __restrict__ emb, const float* __restrict__ gal,
+                                   int32_t* __restrict__ idx_out, float* __restrict__ dist_out,
+                                   int32_t* __restrict__ id_thr_out, float thresh, int B, int G, int D) {
+  const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (b >= B) return;
+  float best = INFINITY;
+  int besti = -1;
+  for (int gi = 0; gi < G; ++gi) {
+    float s2 = 0.f;
+    for (int k = lane; k < D; k += 64) {
+      const float d = (emb[(size_t)b * D + k] - gal[(size_t)gi * D + k]) + 1e-6f;
+      s2 += d * d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+    if (s2 < best) { best = s2; besti = gi; }  // strict <: the first minimum wins (app.py:60)
+  }
+  if (lane == 0) {
+    const float d = besti >= 0 ? sqrtf(best) : INFINITY;
+    idx_out[b] = besti;
+    dist_out[b] = d;
+    if (id_thr_out) id_thr_out[b] = (besti >= 0 && d <= thresh) ? besti : -1;
+  }
 }
 
 __global__ void argkey_finalize_kernel(const unsigned long long* __restrict__ keys, int32_t* __restrict__ out, int B) {
@@ -295,11 +328,18 @@ extern "C" int frmap_l2_normalize_f32(const float* x, float* out, int B, int D, 
 }
 
 extern "C" int frmap_match_top1(const float* emb, const float* gallery, int32_t* idx_out, float* dist_out,
-                                void* workspace, int B, int G, int D, void* stream) {
+                                int32_t* id_or_unknown_out, float thresh, void* workspace, int B, int G, int D,
+                                void* stream) {
   FRMAP_REQUIRE(emb && idx_out && dist_out && workspace, "match_top1: null pointer");
   FRMAP_REQUIRE(B > 0 && D > 0 && D % 4 == 0 && G >= 0, "match_top1: bad shape B=%d G=%d D=%d", B, G, D);
   FRMAP_REQUIRE(G == 0 || gallery, "match_top1: null gallery");
   hipStream_t st = (hipStream_t)stream;
+  if (G > 0 && G <= 64) {
+    hipLaunchKernelGGL(match_small_kernel, dim3(waves_blocks(B)), dim3(256), 0, st, emb, gallery, idx_out, dist_out,
+                       id_or_unknown_out, thresh, B, G, D);
+    FRMAP_LAUNCH_CHECK();
+    return 0;
+  }
   unsigned long long* keys = (unsigned long long*)workspace;
   float* stat_a = (float*)(keys + B);
   float* stat_w = stat_a + 2 * (size_t)B;
@@ -312,7 +352,8 @@ extern "C" int frmap_match_top1(const float* emb, const float* gallery, int32_t*
     int rc = launch_gemm<MODE_DIST>(emb, gallery, B, G, D, ep, st);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(match_finalize_kernel, dim3(waves_blocks(B)), dim3(256), 0, st, emb, gallery, keys, idx_out, dist_out, B, G, D);
+  hipLaunchKernelGGL(match_finalize_kernel, dim3(waves_blocks(B)), dim3(256), 0, st, emb, gallery, keys, idx_out, dist_out,
+                     id_or_unknown_out, thresh, B, G, D);
   FRMAP_LAUNCH_CHECK();
   return 0;
 }

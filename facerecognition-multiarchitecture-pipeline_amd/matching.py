@@ -105,8 +105,7 @@ def embed_and_match(model, x: torch.Tensor, gallery, thresh: float = REC_THRESH,
     if normalize:
         emb = ops.l2_normalize(emb, 1e-12)
     g = _as_gallery(gallery, emb.device)
-    idx, dist = match_batch(emb, g)
-    ids = torch.where(dist <= thresh, idx, torch.full_like(idx, -1))
+    _idx, dist, ids = ops.match_top1(emb.to(torch.float32), g.matrix, thresh)
     return ids, dist
 
 

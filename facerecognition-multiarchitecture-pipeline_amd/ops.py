@@ -201,8 +201,9 @@ def _workspace(B: int, Cc: int, device) -> torch.Tensor:
     return torch.empty(((n + 15) // 16) * 2, dtype=torch.int64, device=device)
 
 
-def match_top1(emb: torch.Tensor, gallery: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """First arg-min over gallery rows of ``||e - g + 1e-6||_2`` and that distance (int32[B], fp32[B])."""
+def match_top1(emb: torch.Tensor, gallery: torch.Tensor, thresh: Optional[float] = None):
+    """First arg-min over gallery rows of ``||e - g + 1e-6||_2`` and that distance (int32[B], fp32[B]).
+    With ``thresh`` a third tensor is returned: idx where dist <= thresh else -1 ("Unknown")."""
     emb = _dev(emb, "match_top1.emb", torch.float32)
     B, D = emb.shape
     G = int(gallery.shape[0]) if gallery is not None else 0
@@ -215,9 +216,12 @@ def match_top1(emb: torch.Tensor, gallery: torch.Tensor) -> Tuple[torch.Tensor, 
     idx = torch.empty((B,), dtype=torch.int32, device=emb.device)
     dist = torch.empty((B,), dtype=torch.float32, device=emb.device)
     ws = _workspace(B, G, emb.device)
-    _lib.check(_lib.load().frmap_match_top1(emb.data_ptr(), gptr, idx.data_ptr(), dist.data_ptr(), ws.data_ptr(),
+    ids = torch.empty((B,), dtype=torch.int32, device=emb.device) if thresh is not None else None
+    _lib.check(_lib.load().frmap_match_top1(emb.data_ptr(), gptr, idx.data_ptr(), dist.data_ptr(),
+                                            ids.data_ptr() if ids is not None else 0,
+                                            float(thresh) if thresh is not None else 0.0, ws.data_ptr(),
                                             B, G, D, _stream()), "match_top1")
-    return idx, dist
+    return (idx, dist) if thresh is None else (idx, dist, ids)
 
 
 def cosine_logits(x: torch.Tensor, w: torch.Tensor, s: float = 1.0, want_logits: bool = True,

@@ -150,6 +150,10 @@ def test_match_top1(B, G, D):
             assert top2 is not None and float(top2[b, 1] - top2[b, 0]) < 1e-6, (b, idx[b], ridx[b])
     assert int(idx[0]) == G // 2 and abs(float(dist[0]) - math.sqrt(D) * 1e-6) < 2e-6
     assert torch.allclose(dist, rdist, atol=2e-6, rtol=1e-5)
+    thr = float(rdist.median())
+    i2, d2, ids = ops.match_top1(pr.to(DEV), gal.to(DEV), thr)
+    assert torch.equal(i2.cpu(), idx) and torch.equal(d2.cpu(), dist)
+    assert torch.equal(ids.cpu(), torch.where(dist <= thr, idx, torch.full_like(idx, -1)))
 
 
 def test_match_top1_edge_cases():
