@@ -272,15 +272,27 @@ __global__ void match_small_kernel(const float* __restrict__ emb, const float* _
   if (b >= B) return;
   float best = INFINITY;
   int besti = -1;
-  for (int gi = 0; gi < G; ++gi) {
-    float s2 = 0.f;
+  // 8 gallery rows at a time: their loads are independent (64+ in flight), then 8 wave reductions
+  for (int g0 = 0; g0 < G; g0 += 8) {
+    float s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s2[j] = 0.f;
     for (int k = lane; k < D; k += 64) {
-      const float d = (emb[(size_t)b * D + k] - gal[(size_t)gi * D + k]) + 1e-6f;
-      s2 += d * d;
+      const float e = emb[(size_t)b * D + k];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int gi = min(g0 + j, G - 1);
+        const float d = (e - gal[(size_t)gi * D + k]) + 1e-6f;
+        s2[j] += d * d;
+      }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
-    if (s2 < best) { best = s2; besti = gi; }  // strict <: the first minimum wins (app.py:60)
+    for (int j = 0; j < 8; ++j) {
+      float v = s2[j];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (g0 + j < G && v < best) { best = v; besti = g0 + j; }  // strict <: the first minimum wins (app.py:60)
+    }
   }
   if (lane == 0) {
     const float d = besti >= 0 ? sqrtf(best) : INFINITY;
