@@ -38,6 +38,9 @@ PROTOTYPES = {
     "frmap_l2_normalize_f32": (_i, [_vp, _vp, _i, _i, _f, _vp]),
     "frmap_cast_to_f32": (_i, [_vp, _vp, _sz, _i, _vp]),
     "frmap_cast_from_f32": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "frmap_add_pos_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
+    "frmap_mha_tokens": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "frmap_mean_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
     "frmap_head_workspace_bytes": (_sz, [_i, _i]),
     "frmap_match_top1": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "frmap_cosine_logits": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),

@@ -71,7 +71,7 @@ __device__ __forceinline__ u32x4_t pack8(const float* f) {
 // Instead each wave transposes 16 pixels at a time through its own LDS scratch (fp32, row pitch
 // NI*64+16 bytes) so that 8 consecutive lanes own one pixel's channel run and every global access
 // (residual load, output store) is 16 bytes per lane and a whole line per 8 (or 4) lanes.
-//   v = acc + shift[c] (+ residual) ; relu ; round once to the storage dtype.
+//   v = acc + shift[c] (+ residual) ; activation (relu: 0 none, 1 ReLU, 2 GELU) ; round once to the storage dtype.
 // Caller guarantees: all waves are past their last read of the LDS tiles (a barrier), `scratch`
 // is this wave's private 16*(NI*64+16)-byte region, 16-byte aligned.
 // ------------------------------------------------------------------------------------------------
@@ -115,9 +115,12 @@ __device__ __forceinline__ void conv_epilogue(const f32x4_t (&acc)[MI][NI], char
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += r[e];
         }
-        if (relu) {
+        if (relu == 1) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (relu == 2) {  // exact (erf) GELU, nn.GELU() default
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));
         }
         *(u32x4_t*)(out + o) = pack8<TT>(v);
       }

@@ -87,9 +87,10 @@ class _PackedLinearAsConv:
         self.wpk = ops.pack_conv_weight(w.reshape(w.shape[0], w.shape[1], 1, 1).contiguous(), dtype)
         self.shift = shift.contiguous()
 
-    def __call__(self, x2d: torch.Tensor, relu: bool) -> torch.Tensor:
+    def __call__(self, x2d: torch.Tensor, relu, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         B, K = x2d.shape
-        y = ops.conv_igemm(x2d.view(B, 1, 1, K), self.wpk, self.shift, self.cout, 1, 1, 0, relu, None)
+        res = residual.view(B, 1, 1, self.cout) if residual is not None else None
+        y = ops.conv_igemm(x2d.view(B, 1, 1, K), self.wpk, self.shift, self.cout, 1, 1, 0, relu, res)
         return y.view(B, self.cout)
 
 
@@ -490,8 +491,7 @@ class ArcFaceNet(_HipModule):
 
 
 # --------------------------------------------------------------------------------------------
-# a7  HybridNet (+ TransformerBlock)  — parameter containers; device path lands with the
-#     transformer kernels
+# a7  HybridNet (+ TransformerBlock)
 # --------------------------------------------------------------------------------------------
 class TransformerBlock(nn.Module):
     """`face_models.py:618-648` (parameter container)."""
@@ -525,14 +525,40 @@ class HybridNet(_HipModule):
         self.fc = nn.Linear(self.fdim, num_classes)
 
     def _build_plan(self, dtype):
-        return {"trunk": _TrunkPlan(self.cnn, dtype)}
+        tr = self.transformer
+        f32 = lambda t: t.detach().float().contiguous()
+        return {
+            "trunk": _TrunkPlan(self.cnn, dtype),
+            "pos": f32(self.pos_encoding).view(self.seq_len, self.fdim),
+            "n1": (f32(tr.norm1.weight), f32(tr.norm1.bias)), "n2": (f32(tr.norm2.weight), f32(tr.norm2.bias)),
+            "nf": (f32(self.norm.weight), f32(self.norm.bias)),
+            "qkv": _PackedLinearAsConv(tr.attention.in_proj_weight, tr.attention.in_proj_bias, None, dtype),
+            "proj": _PackedLinearAsConv(tr.attention.out_proj.weight, tr.attention.out_proj.bias, None, dtype),
+            "ff1": _PackedLinearAsConv(tr.ff[0].weight, tr.ff[0].bias, None, dtype),
+            "ff2": _PackedLinearAsConv(tr.ff[3].weight, tr.ff[3].bias, None, dtype),
+        }
 
     def get_embedding(self, x):
-        raise NotImplementedError("HybridNet: the transformer block kernels are not built yet (SURVEY.md §7 step 8); "
-                                  "the ResNet trunk is available via ResNetTransfer / ArcFaceNet")
+        """`face_models.py:705-721`: trunk (no pool) → +pos → pre-LN transformer block → token mean → LN."""
+        x = self._check_input(x)
+        p = self._get_plan()
+        f = p["trunk"].features(x)                       # NHWC B×7×7×512 == tokens [B][49][512]
+        B, Hh, Ww, D = f.shape
+        L = Hh * Ww
+        if L != self.seq_len:
+            raise ValueError(f"HybridNet expects a {self.seq_len}-token feature map (224×224 input), got {L}")
+        t, n1 = ops.add_pos_layernorm(f.view(B, L, D), p["pos"], *p["n1"], want_sum=True)
+        qkv = p["qkv"](n1.view(B * L, D), relu=0)
+        att = ops.mha_tokens(qkv.view(B, L, 3 * D), self.transformer.attention.num_heads)
+        t2 = p["proj"](att.view(B * L, D), relu=0, residual=t.view(B * L, D))          # x + attn_out
+        _, n2 = ops.add_pos_layernorm(t2.view(B, L, D), None, *p["n2"])
+        hdn = p["ff1"](n2.view(B * L, D), relu=2)                                       # Linear → GELU
+        t3 = p["ff2"](hdn, relu=0, residual=t2)                                          # x + ff_out
+        return ops.mean_layernorm(t3.view(B, L, D), *p["nf"])
 
     def forward(self, x):
-        return self.get_embedding(x)
+        e = self.get_embedding(x)
+        return ops.linear_f32(e, self.fc.weight.detach(), None, self.fc.bias.detach())
 
 
 # --------------------------------------------------------------------------------------------

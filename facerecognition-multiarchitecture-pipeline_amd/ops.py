@@ -105,7 +105,8 @@ def stem7x7_maxpool(x: torch.Tensor, wpk: torch.Tensor, shift: torch.Tensor, dty
 
 
 def conv_igemm(x: torch.Tensor, wpk: torch.Tensor, shift: torch.Tensor, Cout: int, k: int, stride: int, pad: int,
-               relu: bool, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+               relu, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``relu``: False/0 none, True/1 ReLU, 2 exact GELU."""
     x = _dev(x, "conv_igemm.x")
     B, H, W, Cin = x.shape
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
@@ -193,6 +194,41 @@ def cast_from_f32(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     out = torch.empty(x.shape, dtype=dtype, device=x.device)
     _lib.check(_lib.load().frmap_cast_from_f32(x.data_ptr(), out.data_ptr(), x.numel(), dt_code(dtype), _stream()),
                "cast_from_f32")
+    return out
+
+
+def add_pos_layernorm(x: torch.Tensor, pos: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
+                      eps: float = 1e-5, want_sum: bool = False):
+    """x: [B, L, D] tokens.  Returns (t, y): t = x + pos (None unless want_sum), y = LayerNorm(t)."""
+    x = _dev(x, "add_pos_layernorm.x")
+    B, L, D = x.shape
+    y = torch.empty_like(x)
+    t = torch.empty_like(x) if want_sum else None
+    _lib.check(_lib.load().frmap_add_pos_layernorm(
+        x.data_ptr(), _dev(pos, "pos", torch.float32).data_ptr() if pos is not None else 0,
+        _dev(gamma, "gamma", torch.float32).data_ptr(), _dev(beta, "beta", torch.float32).data_ptr(),
+        t.data_ptr() if t is not None else 0, y.data_ptr(), B, L, D, float(eps), dt_code(x.dtype), _stream()),
+        "add_pos_layernorm")
+    return t, y
+
+
+def mha_tokens(qkv: torch.Tensor, H: int) -> torch.Tensor:
+    qkv = _dev(qkv, "mha_tokens.qkv")
+    B, L, D3 = qkv.shape
+    D = D3 // 3
+    out = torch.empty((B, L, D), dtype=qkv.dtype, device=qkv.device)
+    _lib.check(_lib.load().frmap_mha_tokens(qkv.data_ptr(), out.data_ptr(), B, L, D, H, dt_code(qkv.dtype), _stream()),
+               "mha_tokens")
+    return out
+
+
+def mean_layernorm(t: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    t = _dev(t, "mean_layernorm.t")
+    B, L, D = t.shape
+    out = torch.empty((B, D), dtype=torch.float32, device=t.device)
+    _lib.check(_lib.load().frmap_mean_layernorm(t.data_ptr(), _dev(gamma, "gamma", torch.float32).data_ptr(),
+                                                _dev(beta, "beta", torch.float32).data_ptr(), out.data_ptr(), B, L, D,
+                                                float(eps), dt_code(t.dtype), _stream()), "mean_layernorm")
     return out
 
 

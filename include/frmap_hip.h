@@ -80,7 +80,8 @@ int frmap_stem7x7_maxpool(const float* x_nchw, const void* w_packed_c3, const fl
 
 /* ---------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution, NHWC, MFMA 16x16x32 (bf16 / f16), fused epilogue
- *     out = [relu]( conv(in, w) + shift[cout] [+ residual] )
+ *     out = act( conv(in, w) + shift[cout] [+ residual] )      act (`relu` argument): 0 none, 1 ReLU,
+ *                                                              2 exact GELU (nn.GELU, face_models.py:630)
  * Covers: every 3x3 (s1/s2, p1) and 1x1 (s1/s2, p0) convolution + folded BatchNorm (+ReLU)
  * (+ residual add) of the ResNet-18 BasicBlocks behind src/face_models.py:67,463,658, of
  * BaselineNet conv2/conv3 (src/face_models.py:23-26,39-40), of SiameseNet (src/face_models.py:
@@ -125,6 +126,23 @@ int frmap_linear_f32(const float* x, const float* w, const float* scale, const f
 int frmap_l2_normalize_f32(const float* x, float* out, int B, int D, float eps, void* stream);
 int frmap_cast_to_f32(const void* in, float* out, size_t n, int dtype, void* stream);
 int frmap_cast_from_f32(const float* in, void* out, size_t n, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Token-side ops of the hybrid CNN-Transformer (src/face_models.py:618-721), tokens laid out
+ * [B][L][D] in `dtype` (= the NHWC trunk output B×7×7×512 viewed as B×49×512).
+ *   frmap_add_pos_layernorm : t = x (+ pos[l]) ; y = LayerNorm(t)*gamma+beta (eps)   (:639,644,690)
+ *                             t_out (optional) receives t in `dtype`; pos fp32 [L][D] or NULL.
+ *   frmap_mha_tokens        : softmax(QK^T/sqrt(128))V per head of nn.MultiheadAttention(512,4)
+ *                             (:623,640); qkv = [B][L][3D] as in_proj emits; L <= 64, D = H*128.
+ *   frmap_mean_layernorm    : LayerNorm(mean over L tokens) -> fp32 [B][D]               (:718-719)
+ * The projections / MLP GEMMs are frmap_conv_igemm calls (K=1, H=W=1) with bias, GELU, residual fused.
+ * ------------------------------------------------------------------------------------------- */
+int frmap_add_pos_layernorm(const void* x, const float* pos, const float* gamma, const float* beta,
+                            void* t_out, void* y_out, int B, int L, int D, float eps, int dtype,
+                            void* stream);
+int frmap_mha_tokens(const void* qkv, void* out, int B, int L, int D, int H, int dtype, void* stream);
+int frmap_mean_layernorm(const void* t, const float* gamma, const float* beta, float* out_f32,
+                         int B, int L, int D, float eps, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Gallery matching (fp32, exact-f32 MFMA).

@@ -188,6 +188,53 @@ def test_cosine_logits_and_arcmargin(gold_dir):
     assert arg2.cpu().tolist() == arg.cpu().tolist()
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_transformer_token_kernels(dtype):
+    B, L, D, H = 5, 49, 512, 4
+    atol, rtol = _tol(dtype)
+    x = synth.randn(71, (B, L, D), "x").to(dtype)
+    pos = synth.randn(72, (L, D), "p") * 0.1
+    g1, b1 = synth.randn(73, (D,), "g").abs() + 0.5, synth.randn(74, (D,), "b") * 0.1
+    t, y = ops.add_pos_layernorm(x.to(DEV), pos.to(DEV), g1.to(DEV), b1.to(DEV), want_sum=True)
+    t_ref = (x.float() + pos).to(dtype)
+    assert torch.equal(t.cpu(), t_ref)
+    y_ref = F.layer_norm(t_ref.float(), (D,), g1, b1, 1e-5)
+    assert torch.allclose(y.float().cpu(), y_ref, atol=atol * 2, rtol=rtol)
+    _, y2 = ops.add_pos_layernorm(x.to(DEV), None, g1.to(DEV), b1.to(DEV))
+    assert torch.allclose(y2.float().cpu(), F.layer_norm(x.float(), (D,), g1, b1, 1e-5), atol=atol * 2, rtol=rtol)
+    # attention
+    qkv = (synth.randn(75, (B, L, 3 * D), "qkv") * 0.5).to(dtype)
+    o = ops.mha_tokens(qkv.to(DEV), H).float().cpu()
+    q, k, v = qkv.float().split(D, dim=-1)
+    hd = lambda z: z.view(B, L, H, D // H).transpose(1, 2)
+    att = torch.softmax(hd(q) @ hd(k).transpose(-1, -2) / math.sqrt(D // H), dim=-1) @ hd(v)
+    o_ref = att.transpose(1, 2).reshape(B, L, D)
+    assert torch.allclose(o, o_ref, atol=atol, rtol=rtol), (o - o_ref).abs().max()
+    # token mean + LayerNorm
+    m = ops.mean_layernorm(x.to(DEV), g1.to(DEV), b1.to(DEV)).cpu()
+    assert torch.allclose(m, F.layer_norm(x.float().mean(1), (D,), g1, b1, 1e-5), atol=2e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_gelu_residual_on_conv_kernel(dtype):
+    M, K, N = 3 * 49, 512, 2048
+    x = synth.randn(81, (M, K), "x").to(dtype)
+    w = (synth.randn(82, (N, K), "w") / math.sqrt(K)).to(dtype)
+    bias = synth.randn(83, (N,), "b") * 0.1
+    wpk = ops.pack_conv_weight(w.float().view(N, K, 1, 1).to(DEV), dtype)
+    y = ops.conv_igemm(x.view(M, 1, 1, K).to(DEV), wpk, bias.to(DEV), N, 1, 1, 0, 2).view(M, N).float().cpu()
+    ref = F.gelu(x.float() @ w.float().t() + bias)
+    atol, rtol = _tol(dtype)
+    assert torch.allclose(y, ref, atol=atol, rtol=rtol), (y - ref).abs().max()
+    w2 = (synth.randn(84, (K, N), "w2") / math.sqrt(N)).to(dtype)
+    r = synth.randn(85, (M, K), "r").to(dtype)
+    wpk2 = ops.pack_conv_weight(w2.float().view(K, N, 1, 1).to(DEV), dtype)
+    y2 = ops.conv_igemm(y.to(dtype).view(M, 1, 1, N).to(DEV), wpk2, torch.zeros(K, device=DEV), K, 1, 1, 0, 0,
+                        r.view(M, 1, 1, K).to(DEV)).view(M, K).float().cpu()
+    ref2 = y.to(dtype).float() @ w2.float().t() + r.float()
+    assert torch.allclose(y2, ref2, atol=atol * 2, rtol=rtol), (y2 - ref2).abs().max()
+
+
 def test_rejections_do_not_launch():
     with pytest.raises(ValueError):
         ops.conv_igemm(torch.zeros(1, 8, 8, 48, device=DEV, dtype=torch.float16),
