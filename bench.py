@@ -68,11 +68,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; FRMAP_BENCH_BACKEND=gloo lets the N>1 control flow be rehearsed on a 1-GPU box
+    backend = os.environ.get("FRMAP_BENCH_BACKEND", "nccl")
+    local_dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import frmap_amd
     from frmap_amd import dist as fdist
@@ -91,11 +97,15 @@ def main():
     need_norm = args.model in ("cnn", "baseline")
     total = B * world
 
+    def local_step():
+        return frmap_amd.embed_and_match(model, x, gallery, 1.0, normalize=need_norm)
+
     def step():
-        ids, d = frmap_amd.embed_and_match(model, x, gallery, 1.0, normalize=need_norm)
-        if world > 1:
-            ids, d = fdist.gather_results(ids, d, total)
-        return ids, d
+        if world == 1:
+            return local_step()
+        # the match kernel emits the 8-byte (id, distance) records; one all-gather collates them
+        rec = frmap_amd.embed_and_match(model, x, gallery, 1.0, normalize=need_norm, packed=True)
+        return fdist.gather_packed(rec)
 
     with torch.no_grad():
         for _ in range(max(args.warmup, 1) if args.warmup > 0 else 0):
@@ -110,7 +120,7 @@ def main():
         if world > 1:
             dist.barrier()
         t1 = time.perf_counter()
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
@@ -136,7 +146,7 @@ def main():
         try:
             with torch.no_grad():
                 for _ in range(5):
-                    step()
+                    local_step()  # rank-local: no collective outside the timed region
             torch.cuda.synchronize()
         finally:
             fm.ops.conv_igemm = orig
@@ -197,6 +207,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

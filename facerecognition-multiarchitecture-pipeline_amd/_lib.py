@@ -13,7 +13,7 @@ import threading
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libfrmap_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lock = threading.Lock()
 _lib = None
@@ -42,7 +42,7 @@ PROTOTYPES = {
     "frmap_mha_tokens": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "frmap_mean_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
     "frmap_head_workspace_bytes": (_sz, [_i, _i]),
-    "frmap_match_top1": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
+    "frmap_match_top1": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "frmap_cosine_logits": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "frmap_arcmargin_eval": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
 }

@@ -238,13 +238,17 @@ __global__ void fill_u64_kernel(unsigned long long* p, int n, unsigned long long
 // exact distance of the winner, the way F.pairwise_distance forms it: ||(a - g) + eps||_2 in fp32
 __global__ void match_finalize_kernel(const float* __restrict__ emb, const float* __restrict__ gal,
                                       const unsigned long long* __restrict__ keys, int32_t* __restrict__ idx_out,
-                                      float* __restrict__ dist_out, int32_t* __restrict__ id_thr_out, float thresh,
-                                      int B, int G, int D) {
+                                      float* __restrict__ dist_out, int32_t* __restrict__ id_thr_out,
+                                      int32_t* __restrict__ packed_out, float thresh, int B, int G, int D) {
   const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (b >= B) return;
   const unsigned long long key = keys[b];
   if (G <= 0 || key == ~0ull) {
-    if (lane == 0) { idx_out[b] = -1; dist_out[b] = INFINITY; if (id_thr_out) id_thr_out[b] = -1; }
+    if (lane == 0) {
+      idx_out[b] = -1; dist_out[b] = INFINITY;
+      if (id_thr_out) id_thr_out[b] = -1;
+      if (packed_out) { packed_out[2 * b] = -1; packed_out[2 * b + 1] = __float_as_int(INFINITY); }
+    }
     return;
   }
   const int g = (int)(key & 0xFFFFFFFFull);
@@ -258,7 +262,9 @@ __global__ void match_finalize_kernel(const float* __restrict__ emb, const float
   if (lane == 0) {
     const float d = sqrtf(s2);
     idx_out[b] = g; dist_out[b] = d;
-    if (id_thr_out) id_thr_out[b] = d <= thresh ? g : -1;
+    const int idt = d <= thresh ? g : -1;
+    if (id_thr_out) id_thr_out[b] = idt;
+    if (packed_out) { packed_out[2 * b] = idt; packed_out[2 * b + 1] = __float_as_int(d); }
   }
 }
 
@@ -267,7 +273,8 @@ __global__ void match_finalize_kernel(const float* __restrict__ emb, const float
 // expansion, no atomics, one launch.  lane owns dims lane, lane+64, ...
 __global__ void match_small_kernel(const float* __restrict__ emb, const float* __restrict__ gal,
                                    int32_t* __restrict__ idx_out, float* __restrict__ dist_out,
-                                   int32_t* __restrict__ id_thr_out, float thresh, int B, int G, int D) {
+                                   int32_t* __restrict__ id_thr_out, int32_t* __restrict__ packed_out, float thresh,
+                                   int B, int G, int D) {
   const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (b >= B) return;
   float best = INFINITY;
@@ -298,7 +305,9 @@ __global__ void match_small_kernel(const float* __restrict__ emb, const float* _
     const float d = besti >= 0 ? sqrtf(best) : INFINITY;
     idx_out[b] = besti;
     dist_out[b] = d;
-    if (id_thr_out) id_thr_out[b] = (besti >= 0 && d <= thresh) ? besti : -1;
+    const int idt = (besti >= 0 && d <= thresh) ? besti : -1;
+    if (id_thr_out) id_thr_out[b] = idt;
+    if (packed_out) { packed_out[2 * b] = idt; packed_out[2 * b + 1] = __float_as_int(d); }
   }
 }
 
@@ -340,15 +349,15 @@ extern "C" int frmap_l2_normalize_f32(const float* x, float* out, int B, int D, 
 }
 
 extern "C" int frmap_match_top1(const float* emb, const float* gallery, int32_t* idx_out, float* dist_out,
-                                int32_t* id_or_unknown_out, float thresh, void* workspace, int B, int G, int D,
-                                void* stream) {
+                                int32_t* id_or_unknown_out, int32_t* packed_out, float thresh, void* workspace,
+                                int B, int G, int D, void* stream) {
   FRMAP_REQUIRE(emb && idx_out && dist_out && workspace, "match_top1: null pointer");
   FRMAP_REQUIRE(B > 0 && D > 0 && D % 4 == 0 && G >= 0, "match_top1: bad shape B=%d G=%d D=%d", B, G, D);
   FRMAP_REQUIRE(G == 0 || gallery, "match_top1: null gallery");
   hipStream_t st = (hipStream_t)stream;
   if (G > 0 && G <= 64) {
     hipLaunchKernelGGL(match_small_kernel, dim3(waves_blocks(B)), dim3(256), 0, st, emb, gallery, idx_out, dist_out,
-                       id_or_unknown_out, thresh, B, G, D);
+                       id_or_unknown_out, packed_out, thresh, B, G, D);
     FRMAP_LAUNCH_CHECK();
     return 0;
   }
@@ -365,7 +374,7 @@ extern "C" int frmap_match_top1(const float* emb, const float* gallery, int32_t*
     if (rc) return rc;
   }
   hipLaunchKernelGGL(match_finalize_kernel, dim3(waves_blocks(B)), dim3(256), 0, st, emb, gallery, keys, idx_out, dist_out,
-                     id_or_unknown_out, thresh, B, G, D);
+                     id_or_unknown_out, packed_out, thresh, B, G, D);
   FRMAP_LAUNCH_CHECK();
   return 0;
 }

@@ -50,15 +50,36 @@ def gather_results(ids: torch.Tensor, dists: torch.Tensor, total: int,
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     per = -(-total // world)
     packed = pack_results(ids, dists)
+    out_dev = packed.device
+    if dist.get_backend(group) == "gloo" and packed.is_cuda:
+        packed = packed.cpu()  # gloo collectives run on host memory (CPU rehearsal of the N>1 path)
     send = torch.full((per,), -1, dtype=torch.int64, device=packed.device)
     send[: packed.numel()] = packed
     recv = torch.empty((world * per,), dtype=torch.int64, device=packed.device)
     dist.all_gather_into_tensor(recv, send, group=group)
+    recv = recv.to(out_dev)
     parts = []
     for r in range(world):
         lo, hi = shard_bounds(total, r, world)
         parts.append(recv[r * per: r * per + (hi - lo)])
     return unpack_results(torch.cat(parts))
+
+
+def gather_packed(records: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Equal-shard fast path: ``records`` = this rank's int32 ``[B, 2]`` (id, bits(dist)) straight from
+    the match kernel; ONE ``all_gather_into_tensor`` and two zero-copy views, no pack/unpack kernels.
+    Returns (ids int32[world*B], dists fp32[world*B]) — strided views of the gathered buffer."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        recv = records
+    else:
+        world = dist.get_world_size(group)
+        send = records
+        if dist.get_backend(group) == "gloo" and send.is_cuda:
+            send = send.cpu()
+        recv = torch.empty((world * send.shape[0], 2), dtype=torch.int32, device=send.device)
+        dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
+        recv = recv.to(records.device)
+    return recv[:, 0], recv.view(torch.float32)[:, 1]
 
 
 def sharded_embed_and_match(match_fn: Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]],

@@ -94,17 +94,20 @@ def compare_faces(emb, refs, thresh):
 
 
 def embed_and_match(model, x: torch.Tensor, gallery, thresh: float = REC_THRESH,
-                    normalize: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+                    normalize: bool = False, packed: bool = False):
     """Embed a batch and match every face.  Returns ``(ids int32[B], dists fp32[B])`` on the device,
     ``ids[b] = -1`` where the best distance exceeds ``thresh`` (compare_faces' "Unknown").
     ``normalize=True`` L2-normalises the embeddings first (for models whose embedding is not
-    unit-norm: 'baseline', 'cnn', 'hybrid')."""
+    unit-norm: 'baseline', 'cnn', 'hybrid').  ``packed=True`` returns instead the int32 ``[B, 2]``
+    record tensor ``(id, bits(dist))`` the multi-GPU all-gather ships (``dist.gather_packed``)."""
     emb = model.get_embedding(x)
     if emb.dim() == 1:
         emb = emb.unsqueeze(0)
     if normalize:
         emb = ops.l2_normalize(emb, 1e-12)
     g = _as_gallery(gallery, emb.device)
+    if packed:
+        return ops.match_top1(emb.to(torch.float32), g.matrix, thresh, packed=True)[3]
     _idx, dist, ids = ops.match_top1(emb.to(torch.float32), g.matrix, thresh)
     return ids, dist
 

@@ -237,9 +237,10 @@ def _workspace(B: int, Cc: int, device) -> torch.Tensor:
     return torch.empty(((n + 15) // 16) * 2, dtype=torch.int64, device=device)
 
 
-def match_top1(emb: torch.Tensor, gallery: torch.Tensor, thresh: Optional[float] = None):
+def match_top1(emb: torch.Tensor, gallery: torch.Tensor, thresh: Optional[float] = None, packed: bool = False):
     """First arg-min over gallery rows of ``||e - g + 1e-6||_2`` and that distance (int32[B], fp32[B]).
-    With ``thresh`` a third tensor is returned: idx where dist <= thresh else -1 ("Unknown")."""
+    With ``thresh`` a third tensor is returned: idx where dist <= thresh else -1 ("Unknown");
+    with ``packed`` a fourth: int32[B, 2] = (id-or-unknown, bits of dist), the all-gather record."""
     emb = _dev(emb, "match_top1.emb", torch.float32)
     B, D = emb.shape
     G = int(gallery.shape[0]) if gallery is not None else 0
@@ -253,10 +254,14 @@ def match_top1(emb: torch.Tensor, gallery: torch.Tensor, thresh: Optional[float]
     dist = torch.empty((B,), dtype=torch.float32, device=emb.device)
     ws = _workspace(B, G, emb.device)
     ids = torch.empty((B,), dtype=torch.int32, device=emb.device) if thresh is not None else None
+    pk = torch.empty((B, 2), dtype=torch.int32, device=emb.device) if packed else None
     _lib.check(_lib.load().frmap_match_top1(emb.data_ptr(), gptr, idx.data_ptr(), dist.data_ptr(),
                                             ids.data_ptr() if ids is not None else 0,
-                                            float(thresh) if thresh is not None else 0.0, ws.data_ptr(),
+                                            pk.data_ptr() if pk is not None else 0,
+                                            float(thresh) if thresh is not None else float("inf"), ws.data_ptr(),
                                             B, G, D, _stream()), "match_top1")
+    if packed:
+        return idx, dist, ids, pk
     return (idx, dist) if thresh is None else (idx, dist, ids)
 
 

@@ -151,7 +151,9 @@ int frmap_mean_layernorm(const void* t, const float* gamma, const float* beta, f
  *                      the batched form of compare_faces' loop (src/app.py:58-63; F.pairwise_distance
  *                      eps semantics).  idx_out int32[B], dist_out fp32[B].  G == 0 -> idx -1,
  *                      dist +inf.  id_or_unknown_out (optional int32[B]) = idx if dist <= thresh else -1
- *                      (compare_faces' "Unknown", src/app.py:64).  G <= 64 takes a one-launch exact path.
+ *                      (compare_faces' "Unknown", src/app.py:64).  packed_out (optional int32[B][2]) =
+ *                      {id_or_unknown, bits of dist}: the 8-byte record the multi-GPU all-gather ships.
+ *                      G <= 64 takes a one-launch exact path.
  *   frmap_cosine_logits : logits[b][c] = s * <x_b/||x_b||, w_c/||w_c||>  and (optionally)
  *                      argmax_out[b] — class-centre match (src/hyperparameter_tuning.py:1038-1046,
  *                      src/face_models.py:889-893).  logits_out may be NULL.
@@ -164,8 +166,8 @@ int frmap_mean_layernorm(const void* t, const float* gamma, const float* beta, f
  * aligned); C = G for frmap_match_top1. */
 size_t frmap_head_workspace_bytes(int B, int C);
 int frmap_match_top1(const float* emb, const float* gallery, int32_t* idx_out, float* dist_out,
-                     int32_t* id_or_unknown_out, float thresh, void* workspace, int B, int G, int D,
-                     void* stream);
+                     int32_t* id_or_unknown_out, int32_t* packed_out, float thresh, void* workspace,
+                     int B, int G, int D, void* stream);
 int frmap_cosine_logits(const float* x, const float* w, float* logits_out, int32_t* argmax_out,
                         void* workspace, int B, int C, int D, float s, void* stream);
 int frmap_arcmargin_eval(const float* x, const float* w, const int64_t* label, float* logits_out,

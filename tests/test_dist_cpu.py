@@ -29,7 +29,13 @@ def _worker(rank, world, port, total, q):
         ids, d = fdist.sharded_embed_and_match(_fake_match, x, total)
         lo, hi = fdist.shard_bounds(total, rank, world)
         ids2, d2 = fdist.sharded_embed_and_match(_fake_match, x[lo:hi], total, already_sharded=True)
-        q.put((rank, ids.tolist(), d.tolist(), ids2.tolist() == ids.tolist() and d2.tolist() == d.tolist()))
+        same = ids2.tolist() == ids.tolist() and d2.tolist() == d.tolist()
+        if total % world == 0:   # equal shards: the packed fast path must agree too
+            mi, md = _fake_match(x[lo:hi])
+            rec = torch.stack([mi, md.view(torch.int32)], dim=1)
+            i3, d3 = fdist.gather_packed(rec)
+            same = same and i3.tolist() == ids.tolist() and d3.tolist() == d.tolist()
+        q.put((rank, ids.tolist(), d.tolist(), same))
     finally:
         dist.destroy_process_group()
 

@@ -154,6 +154,8 @@ def test_match_top1(B, G, D):
     i2, d2, ids = ops.match_top1(pr.to(DEV), gal.to(DEV), thr)
     assert torch.equal(i2.cpu(), idx) and torch.equal(d2.cpu(), dist)
     assert torch.equal(ids.cpu(), torch.where(dist <= thr, idx, torch.full_like(idx, -1)))
+    pk = ops.match_top1(pr.to(DEV), gal.to(DEV), thr, packed=True)[3].cpu()
+    assert torch.equal(pk[:, 0], ids.cpu()) and torch.equal(pk.view(torch.float32)[:, 1], dist)
 
 
 def test_match_top1_edge_cases():
