@@ -41,6 +41,9 @@ PROTOTYPES = {
     "frmap_add_pos_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
     "frmap_mha_tokens": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "frmap_mean_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
+    "frmap_normalize_u8_hwc": (_i, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _vp]),
+    "frmap_softmax_argmax": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "frmap_pairwise_distance": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
     "frmap_head_workspace_bytes": (_sz, [_i, _i]),
     "frmap_match_top1": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "frmap_cosine_logits": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),

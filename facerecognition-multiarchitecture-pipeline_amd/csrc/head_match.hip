@@ -325,6 +325,53 @@ __global__ void minmax_finalize_kernel(const unsigned int* k, float* out) {
   out[1] = f32_unordered(k[1]);
 }
 
+// row softmax + arg-max (first maximum), one wave per row: `probs = F.softmax(outputs, dim=1)`,
+// `_, predicted = torch.max(outputs, 1)` of the evaluation loop (src/testing.py:278-279)
+__global__ void softmax_argmax_kernel(const float* __restrict__ x, float* __restrict__ probs, int32_t* __restrict__ pred,
+                                      int R, int C) {
+  const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (r >= R) return;
+  float mx = -INFINITY;
+  int mi = 0x7FFFFFFF;
+  for (int c = lane; c < C; c += 64) {
+    const float v = x[(size_t)r * C + c];
+    if (v > mx || (v == mx && c < mi)) { mx = v; mi = c; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(mx, o, 64);
+    const int oi = __shfl_xor(mi, o, 64);
+    if (ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; }
+  }
+  float sum = 0.f;
+  for (int c = lane; c < C; c += 64) sum += __expf(x[(size_t)r * C + c] - mx);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  if (probs)
+    for (int c = lane; c < C; c += 64) probs[(size_t)r * C + c] = __expf(x[(size_t)r * C + c] - mx) / sum;
+  if (pred && lane == 0) pred[r] = mi;
+}
+
+// F.pairwise_distance(a, b) row-wise (eps = 1e-6 on the difference) and the Siamese decision
+// `pred = dist < thresh` (src/testing.py:175-177)
+__global__ void pairwise_distance_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                         float* __restrict__ dist, int32_t* __restrict__ same, float thresh, int R, int D) {
+  const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (r >= R) return;
+  float s2 = 0.f;
+  for (int k = lane; k < D; k += 64) {
+    const float d = (a[(size_t)r * D + k] - b[(size_t)r * D + k]) + 1e-6f;
+    s2 += d * d;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+  if (lane == 0) {
+    const float d = sqrtf(s2);
+    dist[r] = d;
+    if (same) same[r] = d < thresh ? 1 : 0;
+  }
+}
+
 extern "C" size_t frmap_head_workspace_bytes(int B, int C) {
   return (size_t)16 * ((size_t)(B > 0 ? B : 0) + (size_t)(C > 0 ? C : 0)) + 256;
 }
@@ -344,6 +391,23 @@ extern "C" int frmap_l2_normalize_f32(const float* x, float* out, int B, int D, 
   FRMAP_REQUIRE(x && out, "l2_normalize: null pointer");
   FRMAP_REQUIRE(B > 0 && D > 0, "l2_normalize: bad shape");
   hipLaunchKernelGGL(l2_normalize_kernel, dim3(waves_blocks(B)), dim3(256), 0, (hipStream_t)stream, x, out, B, D, eps);
+  FRMAP_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int frmap_softmax_argmax(const float* logits, float* probs_out, int32_t* pred_out, int B, int C, void* stream) {
+  FRMAP_REQUIRE(logits && (probs_out || pred_out), "softmax_argmax: null pointer");
+  FRMAP_REQUIRE(B > 0 && C > 0, "softmax_argmax: bad shape");
+  hipLaunchKernelGGL(softmax_argmax_kernel, dim3(waves_blocks(B)), dim3(256), 0, (hipStream_t)stream, logits, probs_out, pred_out, B, C);
+  FRMAP_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int frmap_pairwise_distance(const float* a, const float* b, float* dist_out, int32_t* same_out, float thresh,
+                                       int B, int D, void* stream) {
+  FRMAP_REQUIRE(a && b && dist_out, "pairwise_distance: null pointer");
+  FRMAP_REQUIRE(B > 0 && D > 0, "pairwise_distance: bad shape");
+  hipLaunchKernelGGL(pairwise_distance_kernel, dim3(waves_blocks(B)), dim3(256), 0, (hipStream_t)stream, a, b, dist_out, same_out, thresh, B, D);
   FRMAP_LAUNCH_CHECK();
   return 0;
 }

@@ -296,3 +296,52 @@ extern "C" int frmap_cast_from_f32(const float* in, void* out, size_t n, int dty
   FRMAP_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// uint8 HWC RGB -> normalised tensor: transforms.ToTensor() (u/255) + transforms.Normalize(mean, std)
+// ((x - mean)/std), the step in front of the hot path (src/testing.py:99-104; src/app.py:39-42).
+// One thread = one pixel.  Writes fp32 NCHW (what the reference modules take) and/or NHWC4 `dtype`
+// (what the first-layer kernels take) — 3 bytes in per pixel instead of 12.
+// ------------------------------------------------------------------------------------------------
+template <typename TT>
+__global__ void normalize_u8_kernel(const unsigned char* __restrict__ img, float* __restrict__ out_nchw,
+                                    typename TT::elem* __restrict__ out_nhwc4, size_t npix, size_t HW, float m0,
+                                    float m1, float m2, float s0, float s1, float s2) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < npix; i += stride) {
+    const float r = ((float)img[i * 3 + 0] / 255.0f - m0) / s0;
+    const float g = ((float)img[i * 3 + 1] / 255.0f - m1) / s1;
+    const float b = ((float)img[i * 3 + 2] / 255.0f - m2) / s2;
+    if (out_nchw) {
+      const size_t n = i / HW, sp = i - n * HW;
+      float* o = out_nchw + n * 3 * HW + sp;
+      o[0] = r; o[HW] = g; o[2 * HW] = b;
+    }
+    if (out_nhwc4) {
+      typename TT::elem e[4] = {TT::from_f32(r), TT::from_f32(g), TT::from_f32(b), TT::from_f32(0.f)};
+      u32x2_t w;
+      __builtin_memcpy(&w, e, 8);
+      *(u32x2_t*)(out_nhwc4 + i * 4) = w;
+    }
+  }
+}
+
+extern "C" int frmap_normalize_u8_hwc(const unsigned char* img, float* out_nchw_f32, void* out_nhwc4, int B, int H,
+                                      int W, const float* mean3_host, const float* std3_host, int dtype, void* stream) {
+  FRMAP_REQUIRE(img && (out_nchw_f32 || out_nhwc4) && mean3_host && std3_host, "normalize_u8_hwc: null pointer");
+  FRMAP_REQUIRE(B > 0 && H > 0 && W > 0, "normalize_u8_hwc: empty input");
+  FRMAP_REQUIRE(dtype == FRMAP_BF16 || dtype == FRMAP_F16, "normalize_u8_hwc: bad dtype");
+  FRMAP_REQUIRE(std3_host[0] != 0.f && std3_host[1] != 0.f && std3_host[2] != 0.f, "normalize_u8_hwc: zero std");
+  const size_t HW = (size_t)H * W, npix = (size_t)B * HW;
+  const int blocks = (int)((npix + 255) / 256 < 16384 ? (npix + 255) / 256 : 16384);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == FRMAP_BF16)
+    hipLaunchKernelGGL(normalize_u8_kernel<BF16>, dim3(blocks), dim3(256), 0, st, img, out_nchw_f32, (__bf16*)out_nhwc4, npix, HW,
+                       mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
+  else
+    hipLaunchKernelGGL(normalize_u8_kernel<F16>, dim3(blocks), dim3(256), 0, st, img, out_nchw_f32, (_Float16*)out_nhwc4, npix, HW,
+                       mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
+  FRMAP_LAUNCH_CHECK();
+  return 0;
+}

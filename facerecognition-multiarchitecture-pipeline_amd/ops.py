@@ -232,6 +232,49 @@ def mean_layernorm(t: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps
     return out
 
 
+def normalize_u8(img: torch.Tensor, mean, std, want_nchw: bool = True, nhwc4_dtype: Optional[torch.dtype] = None):
+    """uint8 [B, H, W, 3] RGB on the GPU → ToTensor + Normalize.  Returns (fp32 NCHW | None, NHWC4 | None)."""
+    import ctypes as C
+    if not isinstance(img, torch.Tensor) or img.dtype != torch.uint8 or img.dim() != 4 or img.shape[3] != 3:
+        raise TypeError("normalize_u8: expected a uint8 tensor of shape [B, H, W, 3]")
+    img = _dev(img, "normalize_u8.img")
+    B, H, W, _ = img.shape
+    o1 = torch.empty((B, 3, H, W), dtype=torch.float32, device=img.device) if want_nchw else None
+    o2 = torch.empty((B, H, W, 4), dtype=nhwc4_dtype, device=img.device) if nhwc4_dtype is not None else None
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    sd = (C.c_float * 3)(*[float(v) for v in std])
+    _lib.check(_lib.load().frmap_normalize_u8_hwc(img.data_ptr(), o1.data_ptr() if o1 is not None else 0,
+                                                  o2.data_ptr() if o2 is not None else 0, B, H, W, m, sd,
+                                                  dt_code(nhwc4_dtype) if nhwc4_dtype is not None else BF16, _stream()),
+               "normalize_u8")
+    return o1, o2
+
+
+def softmax_argmax(logits: torch.Tensor, want_probs: bool = True):
+    logits = _dev(logits, "softmax_argmax.logits", torch.float32)
+    B, Cc = logits.shape
+    probs = torch.empty_like(logits) if want_probs else None
+    pred = torch.empty((B,), dtype=torch.int32, device=logits.device)
+    _lib.check(_lib.load().frmap_softmax_argmax(logits.data_ptr(), probs.data_ptr() if want_probs else 0, pred.data_ptr(),
+                                                B, Cc, _stream()), "softmax_argmax")
+    return probs, pred
+
+
+def pairwise_distance(a: torch.Tensor, b: torch.Tensor, thresh: Optional[float] = None):
+    a = _dev(a, "pairwise_distance.a", torch.float32)
+    b = _dev(b, "pairwise_distance.b", torch.float32)
+    if a.shape != b.shape or a.dim() != 2:
+        raise ValueError("pairwise_distance: need two [B, D] tensors of the same shape")
+    B, D = a.shape
+    dist = torch.empty((B,), dtype=torch.float32, device=a.device)
+    same = torch.empty((B,), dtype=torch.int32, device=a.device) if thresh is not None else None
+    _lib.check(_lib.load().frmap_pairwise_distance(a.data_ptr(), b.data_ptr(), dist.data_ptr(),
+                                                   same.data_ptr() if same is not None else 0,
+                                                   float(thresh) if thresh is not None else 0.0, B, D, _stream()),
+               "pairwise_distance")
+    return dist, same
+
+
 def _workspace(B: int, Cc: int, device) -> torch.Tensor:
     n = _lib.load().frmap_head_workspace_bytes(B, Cc)
     return torch.empty(((n + 15) // 16) * 2, dtype=torch.int64, device=device)

@@ -42,6 +42,12 @@ const char* frmap_last_error(void);
 int frmap_pack_input_nchw_f32(const float* x_nchw, void* out_nhwc4, int B, int H, int W,
                               int dtype, void* stream);
 
+/* uint8 HWC RGB B×H×W×3 -> ToTensor (u/255) + Normalize ((x-mean)/std), src/testing.py:99-104,
+ * src/app.py:39-42.  Writes fp32 NCHW (out_nchw_f32) and/or NHWC4 `dtype` (out_nhwc4); either may be
+ * NULL.  mean3_host / std3_host: 3 floats each in HOST memory. */
+int frmap_normalize_u8_hwc(const unsigned char* img_u8, float* out_nchw_f32, void* out_nhwc4, int B, int H,
+                           int W, const float* mean3_host, const float* std3_host, int dtype, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Conv weight packing.  `w_oihw` = fp32 [Cout][Cin][KH][KW] with the BatchNorm scale already
  * folded in (w * gamma/sqrt(var+eps)); output is the kernel's LDS-image order in `dtype`.
@@ -162,6 +168,13 @@ int frmap_mean_layernorm(const void* t, const float* gamma, const float* beta, f
  *                      easy-margin rule) -> * min(s,24) -> NaN/Inf -> 0.  label: int64[B].
  *                      minmax_out (optional) fp32[2] receives max/min raw cosine (:358-360).
  * ------------------------------------------------------------------------------------------- */
+/* Evaluation-loop glue (src/testing.py:175-177, 278-279):
+ *   frmap_softmax_argmax    : probs = softmax(logits, dim=1) (optional), pred = first arg-max (optional)
+ *   frmap_pairwise_distance : dist[b] = ||a_b - b_b + 1e-6||_2 ; same_out[b] = dist < thresh (optional) */
+int frmap_softmax_argmax(const float* logits, float* probs_out, int32_t* pred_out, int B, int C, void* stream);
+int frmap_pairwise_distance(const float* a, const float* b, float* dist_out, int32_t* same_out, float thresh,
+                            int B, int D, void* stream);
+
 /* Scratch each of the three calls below needs (device, caller-owned, >= this many bytes, 16-byte
  * aligned); C = G for frmap_match_top1. */
 size_t frmap_head_workspace_bytes(int B, int C);

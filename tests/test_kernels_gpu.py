@@ -237,6 +237,28 @@ def test_linear_gelu_residual_on_conv_kernel(dtype):
     assert torch.allclose(y2, ref2, atol=atol * 2, rtol=rtol), (y2 - ref2).abs().max()
 
 
+def test_preprocess_and_eval_glue():
+    from frmap_amd import evaluate
+    g = np.random.Generator(np.random.PCG64(91))
+    img = torch.from_numpy(g.integers(0, 256, (3, 40, 36, 3), dtype=np.uint8))
+    for mean, std in ((evaluate.IMAGENET_MEAN, evaluate.IMAGENET_STD), (evaluate.FACENET_MEAN, evaluate.FACENET_STD)):
+        ref = (img.permute(0, 3, 1, 2).float().div(255) - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+        out = evaluate.preprocess(img, mean, std)
+        assert torch.allclose(out.cpu(), ref, atol=1e-6, rtol=1e-6), (out.cpu() - ref).abs().max()
+        _, x4 = ops.normalize_u8(img.to(DEV), mean, std, want_nchw=False, nhwc4_dtype=torch.float16)
+        assert torch.equal(x4[..., :3].float().cpu(), ref.permute(0, 2, 3, 1).to(torch.float16).float())
+        assert float(x4[..., 3].abs().max()) == 0.0
+    logits = synth.randn(92, (37, 36), "l") * 3
+    logits[5, 7] = logits[5, 11] = logits[5].max() + 1.0           # tie: first index wins (torch.max semantics)
+    probs, pred = ops.softmax_argmax(logits.to(DEV))
+    assert torch.allclose(probs.cpu(), F.softmax(logits, dim=1), atol=1e-6)
+    assert pred.cpu().tolist() == logits.argmax(1).tolist() and int(pred[5]) == 7
+    a, b = synth.randn(93, (19, 256), "a"), synth.randn(94, (19, 256), "b")
+    d, same = ops.pairwise_distance(a.to(DEV), b.to(DEV), 22.6)
+    dref = F.pairwise_distance(a, b)
+    assert torch.allclose(d.cpu(), dref, rtol=1e-6) and same.cpu().tolist() == (dref < 22.6).int().tolist()
+
+
 def test_rejections_do_not_launch():
     with pytest.raises(ValueError):
         ops.conv_igemm(torch.zeros(1, 8, 8, 48, device=DEV, dtype=torch.float16),

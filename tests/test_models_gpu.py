@@ -156,3 +156,37 @@ def test_state_dict_reload_invalidates_plan(calibrated_sd):
     m.train()
     with pytest.raises(NotImplementedError):
         m(x)
+
+
+def test_eval_step_and_siamese_verify(gold_dir, calibrated_sd):
+    """The callers around the path: testing.py's forward→softmax→argmax step, the
+    ArcFace class-centre scoring, and the Siamese dist<0.5 decision, against the CPU oracle."""
+    from frmap_amd import evaluate
+    sd = calibrated_sd("baseline")
+    x = weights.golden_inputs("baseline", 8)
+    m = _model("baseline", sd, torch.float16)
+    out, probs, pred = evaluate.predict_batch(m, x.to(DEV), "baseline")
+    ref = fo.baseline_forward(sd, x)
+    assert torch.allclose(probs.cpu(), F.softmax(ref, 1), atol=2e-3)
+    assert pred.cpu().tolist() == ref.argmax(1).tolist()
+    sd = calibrated_sd("arcface")
+    x = weights.golden_inputs("arcface", 8)
+    m = _model("arcface", sd, torch.float16)
+    logits, arg = evaluate.arcface_validate(m, x.to(DEV))
+    rl, ra = fo.class_centre_match(fo.arcface_embedding(sd, x), sd["arcface.weight"], 32.0)
+    assert torch.allclose(logits.cpu(), rl, atol=0.05)
+    top2 = rl.topk(2, dim=1).values
+    margin = top2[:, 0] - top2[:, 1]          # random class centres: some rows are near-ties
+    out, probs, pred = evaluate.predict_batch(m, x.to(DEV), "arcface")
+    for b in range(8):
+        if margin[b] > 0.1:                   # decisions must agree wherever fp16 error cannot flip them
+            assert int(arg[b]) == int(ra[b]) == int(pred[b]), b
+    assert (margin > 0.1).sum() >= 4
+    assert int(arg.cpu()[0]) == int(logits.cpu()[0].argmax())   # arg-max is consistent with its own logits
+    sd = calibrated_sd("siamese")
+    x = weights.golden_inputs("siamese", 8)
+    m = _model("siamese", sd, torch.float16)
+    z = np.load(os.path.join(gold_dir, "siamese.npz"))
+    d, p = evaluate.siamese_verify(m, x[:4].to(DEV), x[4:8].to(DEV))
+    rd, rp = fo.siamese_decision(*fo.siamese_forward(sd, x[:4], x[4:8]))
+    assert torch.allclose(d.cpu(), rd, atol=2e-2) and p.cpu().tolist() == rp.tolist()
