@@ -39,6 +39,11 @@ struct ConvParams {
   int dbg;  // timing ablations only (FRMAP_CONV_DEBUG): 1 = stage chunk 0 only, 2 = skip the MFMA loop
 };
 
+__device__ __forceinline__ int xcd_remap_fwd(int b, int nb) {
+  const int qd = nb >> 3, rm = nb & 7, xcd = b & 7;
+  return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (b >> 3);
+}
+
 template <int SWZ>
 __device__ __forceinline__ int px_off(int q, int slot) {
   if (SWZ == 1) return (q << 6) + ((slot ^ (((q >> 2) & 1) << 1)) << 4);
@@ -260,6 +265,115 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   __syncthreads();  // every wave is done reading the staged tiles; LDS is free for the transpose
   conv_epilogue<TT, MI, NI>(acc, smem + wave * (16 * (NI * 64 + 16)), m0 + wave * (BM / 4), p.M, p.Cout, nt << 6,
                             p.shift, (const typename TT::elem*)p.res, (typename TT::elem*)p.out, p.relu, lane);
+}
+
+// ================================================================================================
+// 3x3 stride-2 convolutions: row-parity split staging.
+//
+// A stride-2 output row oy reads input rows 2oy-1, 2oy, 2oy+1: every input row of the tile is needed,
+// 4 input pixels per output pixel, and the full halo of 256 output pixels (~90 KB) leaves room for
+// only one workgroup per CU.  But tap rows kh = 0 and 2 touch only EVEN padded rows and kh = 1 only
+// ODD ones, so each 32-channel chunk is run as two sub-stages — {even rows, 6 taps} then {odd rows,
+// 3 taps} — each with a half-height halo (~48 KB + 24 KB of weights): two workgroups fit per CU again
+// and one stages while the other computes.
+// ================================================================================================
+template <typename TT>
+__global__ __launch_bounds__(256, 2) void conv3x3s2_split_kernel(const ConvParams p) {
+  constexpr int BM = 256, MI = 4, NI = 4;
+  using vec8 = typename TT::vec8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;
+  char* wl = smem + p.halo_bytes;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, g = lane >> 4;
+  const int L = xcd_remap_fwd(blockIdx.x, p.nblocks);
+  const int ntiles = p.Cout >> 6;
+  const int mt = L / ntiles, nt = L - mt * ntiles;
+  const int m0 = mt * BM, mlast = min(m0 + BM, p.M) - 1;
+  const int Hh = p.Hp >> 1;  // padded rows per image and parity
+  const int n0 = m0 / p.HoWo, oy0 = (m0 - n0 * p.HoWo) / p.Wo;
+  const int n1 = mlast / p.HoWo, oy1 = (mlast - n1 * p.HoWo) / p.Wo;
+  const int span = (n1 - n0) * Hh + oy1 - oy0;  // last pixel's row index within a parity plane
+  const int rr0 = 2 * oy0;                       // padded row of the tile's first even row
+
+  int qb[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = min(m0 + wave * 64 + mi * 16 + lr, p.M - 1);
+    const int n = m / p.HoWo, rem = m - n * p.HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    qb[mi] = ((n - n0) * Hh + oy - oy0) * p.Wp + 2 * ox;
+  }
+  const int woff = (lr << 6) + ((g ^ (((lr >> 2) & 1) << 1)) << 4);
+  f32x4_t acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const typename TT::elem* inp = (const typename TT::elem*)p.in;
+
+  for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {  // 0: even padded rows, taps kh in {0,2};  1: odd rows, kh = 1
+      if (chunk > 0 || par > 0) __syncthreads();
+      const int ntap = par ? 3 : 6;
+      const char* wsrc = (const char*)p.wpk + ((size_t)(nt * p.nchunks + chunk) * 9) * 4096 + tid * 16;
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        if (t < ntap) {
+          const int tap = par ? 3 + t : (t < 3 ? t : t + 3);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + tap * 4096),
+                                           (__attribute__((address_space(3))) void*)(wl + t * 4096 + wave * 1024), 16, 0, 0);
+        }
+      }
+      const int nrows = span + (par ? 1 : 2);
+      const int nitems = nrows * p.Wp * 4;
+      constexpr int NB = 8;
+      for (int it0 = tid; it0 < nitems; it0 += 256 * NB) {
+        u32x4_t v[NB];
+        int dst[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          const int item = it0 + u * 256;
+          dst[u] = -1;
+          v[u] = (u32x4_t){0u, 0u, 0u, 0u};
+          if (item < nitems) {
+            const int px = item >> 2, cg = item & 3;
+            const int r = (int)fast_div((uint32_t)px, p.magic_Wp);
+            const int c = px - r * p.Wp;
+            const int rr = rr0 + 2 * r + par;  // padded row in the stack of images
+            const int dn = (int)fast_div((uint32_t)rr, p.magic_Hp);
+            const int iy = rr - dn * p.Hp - 1, ix = c - 1, n = n0 + dn;
+            dst[u] = px_off<2>(px, cg);
+            if (n < p.N && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
+              v[u] = *(const u32x4_t*)(inp + (((size_t)n * p.Hi + iy) * p.Wi + ix) * p.Cin + (size_t)(chunk * 32 + cg * 8));
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u)
+          if (dst[u] >= 0) *(u32x4_t*)(halo + dst[u]) = v[u];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        if (t < ntap) {
+          const int dq = par ? t : (t / 3) * p.Wp + (t % 3);  // even plane: kh=0 -> row +0, kh=2 -> row +1
+          vec8 wf[NI], pf[MI];
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) wf[ni] = *(const vec8*)(wl + t * 4096 + ni * 1024 + woff);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) pf[mi] = *(const vec8*)(halo + px_off<2>(qb[mi] + dq, g));
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = TT::mfma(wf[ni], pf[mi], acc[mi][ni]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  conv_epilogue<TT, MI, NI>(acc, smem + wave * (16 * (NI * 64 + 16)), m0 + wave * 64, p.M, p.Cout, nt << 6, p.shift,
+                            (const typename TT::elem*)p.res, (typename TT::elem*)p.out, p.relu, lane);
 }
 
 // ================================================================================================
@@ -557,6 +671,35 @@ extern "C" int frmap_conv_igemm(const void* in, const void* w_packed, const floa
         hipLaunchKernelGGL((conv3x3_pipe_kernel<BF16, true>), dim3(grid), dim3(256), (int)lds2, st, p);
       else
         hipLaunchKernelGGL((conv3x3_pipe_kernel<F16, true>), dim3(grid), dim3(256), (int)lds2, st, p);
+      FRMAP_LAUNCH_CHECK();
+      return 0;
+    }
+  }
+  // 3x3 stride 2 (even input height): row-parity split staging, two workgroups per CU
+  if (stride == 2 && Hi % 2 == 0 && p.dbg == 0) {
+    const int rows = (256 + Wo - 2) / Wo + 1, cross = (256 + Ho * Wo - 2) / (Ho * Wo);
+    const int x = cross < rows - 1 ? cross : rows - 1;
+    const int step = p.Hp / 2 - (Ho - 1);
+    long long hbs = (long long)((rows - 1 - x) + x * (step > 1 ? step : 1) + 2) * p.Wp * 64;
+    hbs = (hbs + 1023) & ~1023ll;
+    if (hbs + 6 * 4096 <= 80 * 1024 && hbs / 64 < 65536) {
+      p.halo_bytes = (int)hbs;
+      p.nblocks = ((p.M + 255) / 256) * ntiles;
+      const int lds = (int)hbs + 6 * 4096;
+      static bool attr[2] = {false, false};
+      const void* kern = dtype == FRMAP_BF16 ? (const void*)conv3x3s2_split_kernel<BF16> : (const void*)conv3x3s2_split_kernel<F16>;
+      if (!attr[dtype]) {
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+          frmap_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+          return -2;
+        }
+        attr[dtype] = true;
+      }
+      if (dtype == FRMAP_BF16)
+        hipLaunchKernelGGL(conv3x3s2_split_kernel<BF16>, dim3(p.nblocks), dim3(256), lds, st, p);
+      else
+        hipLaunchKernelGGL(conv3x3s2_split_kernel<F16>, dim3(p.nblocks), dim3(256), lds, st, p);
       FRMAP_LAUNCH_CHECK();
       return 0;
     }

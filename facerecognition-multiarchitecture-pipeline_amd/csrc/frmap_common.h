@@ -96,6 +96,19 @@ __device__ __forceinline__ void conv_epilogue(const f32x4_t (&acc)[MI][NI], char
     sh[j][0] = s0[0]; sh[j][1] = s0[1]; sh[j][2] = s0[2]; sh[j][3] = s0[3];
     sh[j][4] = s1[0]; sh[j][5] = s1[1]; sh[j][6] = s1[2]; sh[j][7] = s1[3];
   }
+  // residual: all of this lane's 16-byte pieces are requested up front (one global round trip,
+  // not one per pass); they land while the LDS transposes run
+  u32x4_t rv[MI][PER_LANE];
+  if (res) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int j = 0; j < PER_LANE; ++j) {
+        const int m = m_wave0 + mi * 16 + prow[j];
+        rv[mi][j] = (u32x4_t){0u, 0u, 0u, 0u};
+        if (m < M) rv[mi][j] = *(const u32x4_t*)(res + (size_t)m * Cout + co0 + part[j] * 8);
+      }
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -111,7 +124,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x4_t (&acc)[MI][NI], char
                       b[0] + sh[j][4], b[1] + sh[j][5], b[2] + sh[j][6], b[3] + sh[j][7]};
         if (res) {
           float r[8];
-          unpack8<TT>(*(const u32x4_t*)(res + o), r);
+          unpack8<TT>(rv[mi][j], r);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += r[e];
         }
