@@ -39,6 +39,10 @@ struct ConvParams {
   int dbg;  // timing ablations only (FRMAP_CONV_DEBUG): 1 = stage chunk 0 only, 2 = skip the MFMA loop
 };
 
+// 64 zero bytes: out-of-image (padding) pixels LOAD from here instead of branching around the load —
+// a per-element `if (valid) v = load` makes hipcc serialise the loads with a wait each.
+__device__ __attribute__((aligned(64))) unsigned int g_zero_page[16];
+
 __device__ __forceinline__ int xcd_remap_fwd(int b, int nb) {
   const int qd = nb >> 3, rm = nb & 7, xcd = b & 7;
   return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (b >> 3);
@@ -164,8 +168,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   auto prefetch = [&](int chunk) {
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
-      hv[u] = (u32x4_t){0u, 0u, 0u, 0u};
-      if (soff[u] != 0xFFFFFFFFu) hv[u] = *(const u32x4_t*)(inp0 + soff[u] + chunk * 32);
+      const typename TT::elem* a = soff[u] != 0xFFFFFFFFu ? inp0 + soff[u] + chunk * 32 : (const typename TT::elem*)g_zero_page;
+      hv[u] = *(const u32x4_t*)a;  // unconditional: padding reads the zero page
     }
     const char* wsrc = (const char*)p.wpk + ((size_t)(nt * p.nchunks + chunk) * TAPS) * 4096 + tid * 16;
 #pragma unroll
@@ -228,10 +232,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
             const int ix = c - p.pad;
             const int n = n0 + dn;
             dst[u] = px_off<SWZ>(px, cg);
-            if (n < p.N && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) {
-              const size_t src = (((size_t)n * p.Hi + iy) * p.Wi + ix) * p.Cin + (size_t)(chunk * 32 + cg * 8);
-              v[u] = *(const u32x4_t*)(inp + src);
-            }
+            const bool ok = n < p.N && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const size_t src = (((size_t)n * p.Hi + iy) * p.Wi + ix) * p.Cin + (size_t)(chunk * 32 + cg * 8);
+            const typename TT::elem* a = ok ? inp + src : (const typename TT::elem*)g_zero_page;
+            v[u] = *(const u32x4_t*)a;  // unconditional load (see g_zero_page)
           }
         }
 #pragma unroll
@@ -345,8 +349,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_split_kernel(const ConvParam
             const int dn = (int)fast_div((uint32_t)rr, p.magic_Hp);
             const int iy = rr - dn * p.Hp - 1, ix = c - 1, n = n0 + dn;
             dst[u] = px_off<2>(px, cg);
-            if (n < p.N && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
-              v[u] = *(const u32x4_t*)(inp + (((size_t)n * p.Hi + iy) * p.Wi + ix) * p.Cin + (size_t)(chunk * 32 + cg * 8));
+            const bool ok = n < p.N && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const typename TT::elem* a = ok ? inp + (((size_t)n * p.Hi + iy) * p.Wi + ix) * p.Cin + (size_t)(chunk * 32 + cg * 8)
+                                            : (const typename TT::elem*)g_zero_page;
+            v[u] = *(const u32x4_t*)a;  // unconditional load (see g_zero_page)
           }
         }
 #pragma unroll
@@ -374,196 +380,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_split_kernel(const ConvParam
   __syncthreads();
   conv_epilogue<TT, MI, NI>(acc, smem + wave * (16 * (NI * 64 + 16)), m0 + wave * 64, p.M, p.Cout, nt << 6, p.shift,
                             (const typename TT::elem*)p.res, (typename TT::elem*)p.out, p.relu, lane);
-}
-
-// ================================================================================================
-// Pipelined persistent variant for 3x3 stride-1 convolutions (the dominant kernel).
-//
-// Same tiling and LDS images as conv_igemm_kernel, different schedule: ONE workgroup per CU walks
-// tiles (pixel tile x channel tile) and their 32-channel chunks as one continuous stream of
-// "stages".  Every stage's operands (input halo AND weight slab) are fetched by LDS-DMA
-// (global_load_lds_dwordx4: no VGPRs, asynchronous) into the LDS buffer the MFMAs are NOT reading,
-// one stage ahead — across chunk and tile boundaries — so global latency, zero padding and the
-// epilogue of tile t overlap the MFMA phase of the neighbouring stages.  One barrier per stage.
-//   * the halo image is written by the DMA in linear order (lane-linear destination), so the XOR
-//     swizzle is applied on the SOURCE side: lane i of a 1 KB piece fetches pixel i>>2, channel
-//     group (i&3) ^ swz(pixel); padding pixels fetch from a 16-byte zero page.
-//   * waits are explicit: `s_waitcnt vmcnt(N)` + raw s_barrier (a __syncthreads() would drain the
-//     prefetch).  The only other VMEM traffic is the epilogue's stores, which may stay in flight.
-// ================================================================================================
-__device__ __attribute__((aligned(16))) unsigned int g_zero_page[16];  // zero-initialised
-
-__device__ __forceinline__ int idiv_exact(int n, int d, double rcp) {
-  int q = (int)((double)n * rcp);
-  const int r = n - q * d;
-  if (r < 0) --q; else if (r >= d) ++q;
-  return q;
-}
-
-__device__ __forceinline__ int xcd_remap(int b, int nb) {
-  const int qd = nb >> 3, rm = nb & 7, xcd = b & 7;
-  return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (b >> 3);
-}
-
-// WRES: the whole weight set of the (single) channel tile fits next to two halo buffers, so it is
-// loaded ONCE per workgroup and only the input halo streams (Cin = 64, Cout = 64: ResNet layer1).
-template <typename TT, bool WRES>
-__global__ __launch_bounds__(256, 1) void conv3x3_pipe_kernel(const ConvParams p) {
-  constexpr int BM = 256, MI = 4, NI = 4, TAPS = 9, WBYTES = TAPS * 4096, NHMAX = 10;
-  using vec8 = typename TT::vec8;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int SB = WRES ? p.halo_bytes : p.halo_bytes + WBYTES;  // one stage buffer: [halo image][weight slab]
-  char* wres = smem + 2 * SB;                                  // WRES: [nchunks][weight slab] after the two halo buffers
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lr = lane & 15, g = lane >> 4;
-  const int ntl = p.Cout >> 6;
-  const int ntiles = p.nblocks;  // total (pixel tile, channel tile) pairs
-  const int G = gridDim.x;
-  const double rcpHoWo = 1.0 / (double)p.HoWo, rcpWo = 1.0 / (double)p.Wo;
-  const typename TT::elem* inp = (const typename TT::elem*)p.in;
-  const char* zero_src = (const char*)g_zero_page;
-
-  // ---- load-side state: where the DMA of the tile being fetched reads from ----------------------
-  unsigned src_off[NHMAX];  // element offset of each of this thread's halo items (chunk 0); ~0u = zero page
-  int ld_nitems = 0, ld_nt = 0;
-  auto setup_load = [&](int seq) {
-    const int base = (seq / G) * G;
-    const int L = base + xcd_remap(seq - base, min(G, ntiles - base));
-    const int mt = L / ntl;
-    ld_nt = L - mt * ntl;
-    const int m0 = mt * BM, mlast = min(m0 + BM, p.M) - 1;
-    const int n0 = idiv_exact(m0, p.HoWo, rcpHoWo);
-    const int rr0 = idiv_exact(m0 - n0 * p.HoWo, p.Wo, rcpWo);
-    const int n1 = idiv_exact(mlast, p.HoWo, rcpHoWo);
-    const int oy1 = idiv_exact(mlast - n1 * p.HoWo, p.Wo, rcpWo);
-    const int nrows = (n1 - n0) * p.Hp + oy1 - rr0 + 3;
-    ld_nitems = nrows * p.Wp * 4;
-#pragma unroll
-    for (int it = 0; it < NHMAX; ++it) {
-      const int item = it * 256 + tid;
-      const int px = item >> 2;
-      const int cg = (item & 3) ^ (((px >> 2) & 1) << 1);  // inverse of the read-side swizzle
-      const int r = (int)fast_div((uint32_t)px, p.magic_Wp);
-      const int c = px - r * p.Wp;
-      const int rr = rr0 + r;
-      const int dn = (int)fast_div((uint32_t)rr, p.magic_Hp);
-      const int iy = rr - dn * p.Hp - 1, ix = c - 1, n = n0 + dn;
-      const bool ok = item < ld_nitems && n < p.N && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-      src_off[it] = ok ? ((unsigned)((n * p.Hi + iy) * p.Wi + ix) * (unsigned)p.Cin + (unsigned)(cg * 8)) : 0xFFFFFFFFu;
-    }
-  };
-  auto issue_dma = [&](char* buf, int chunk) {
-    // weights: contiguous pre-packed slab, 9 x 4 KB
-    if (!WRES) {
-      const char* wsrc = (const char*)p.wpk + ((size_t)(ld_nt * p.nchunks + chunk) * TAPS) * 4096 + tid * 16;
-#pragma unroll
-      for (int t = 0; t < TAPS; ++t)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + t * 4096),
-                                         (__attribute__((address_space(3))) void*)(buf + p.halo_bytes + t * 4096 + wave * 1024),
-                                         16, 0, 0);
-    }
-    // halo: item i -> LDS byte i*16 (linear); source picked per lane
-#pragma unroll
-    for (int it = 0; it < NHMAX; ++it) {
-      if (it * 256 + wave * 64 < ld_nitems) {  // wave-uniform: this 1 KB piece has at least one live lane
-        const unsigned o = src_off[it];
-        const char* src = (o == 0xFFFFFFFFu) ? zero_src : (const char*)(inp + (size_t)o + (size_t)chunk * 32);
-        if (it * 256 + tid < ld_nitems)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                           (__attribute__((address_space(3))) void*)(buf + (it * 256 + wave * 64) * 16),
-                                           16, 0, 0);
-      }
-    }
-  };
-
-  int seq = blockIdx.x;
-  if (seq >= ntiles) return;
-  if (WRES) {  // the full weight set, once
-    const char* wsrc = (const char*)p.wpk + tid * 16;
-    for (int t = 0; t < p.nchunks * TAPS; ++t)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + t * 4096),
-                                       (__attribute__((address_space(3))) void*)(wres + t * 4096 + wave * 1024), 16, 0, 0);
-  }
-  setup_load(seq);
-  issue_dma(smem, 0);
-  int s = 0;               // global stage counter; stage s lives in buffer s & 1
-  bool after_store = false;  // the previous stage ended with an epilogue whose stores may still be in flight
-  const int woff = (lr << 6) + ((g ^ (((lr >> 2) & 1) << 1)) << 4);
-
-  for (;;) {
-    // ---- compute-side state of the tile whose stages start now ------------------------------------
-    const int base = (seq / G) * G;
-    const int L = base + xcd_remap(seq - base, min(G, ntiles - base));
-    const int mt = L / ntl, nt = L - mt * ntl;
-    const int m0 = mt * BM;
-    const int n0 = idiv_exact(m0, p.HoWo, rcpHoWo);
-    const int rr0 = idiv_exact(m0 - n0 * p.HoWo, p.Wo, rcpWo);
-    int qb[MI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int m = min(m0 + wave * 64 + mi * 16 + lr, p.M - 1);
-      const int n = idiv_exact(m, p.HoWo, rcpHoWo);
-      const int rem = m - n * p.HoWo;
-      const int oy = idiv_exact(rem, p.Wo, rcpWo);
-      qb[mi] = ((n - n0) * p.Hp + oy - rr0) * p.Wp + (rem - oy * p.Wo);
-    }
-    const bool full_tile = m0 + BM <= p.M;
-    f32x4_t acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-    const int next_seq = seq + G;
-    for (int chunk = 0; chunk < p.nchunks; ++chunk, ++s) {
-      // this wave's DMA pieces of stage s have landed (only epilogue stores may be younger) ...
-      if (after_store) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      after_store = false;
-      // ... and everyone's: all waves are also done reading the other buffer (stage s-1)
-      asm volatile("s_barrier" ::: "memory");
-      char* cur = smem + (s & 1) * SB;
-      char* oth = smem + ((s + 1) & 1) * SB;
-      if (chunk + 1 < p.nchunks) {
-        issue_dma(oth, chunk + 1);
-      } else if (next_seq < ntiles) {
-        setup_load(next_seq);
-        issue_dma(oth, 0);
-      }
-      const char* halo = cur;
-      const char* wl = WRES ? wres + chunk * WBYTES : cur + p.halo_bytes;
-      vec8 wf[2][NI], pf[2][MI];
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) wf[0][ni] = *(const vec8*)(wl + ni * 1024 + woff);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) pf[0][mi] = *(const vec8*)(halo + px_off<1>(qb[mi], g));
-#pragma unroll
-      for (int t = 0; t < TAPS; ++t) {
-        const int cu = t & 1, nx = cu ^ 1;
-        if (t + 1 < TAPS) {
-          const int dq = ((t + 1) / 3) * p.Wp + ((t + 1) % 3);
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) wf[nx][ni] = *(const vec8*)(wl + (t + 1) * 4096 + ni * 1024 + woff);
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) pf[nx][mi] = *(const vec8*)(halo + px_off<1>(qb[mi] + dq, g));
-        }
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = TT::mfma(wf[cu][ni], pf[cu][mi], acc[mi][ni]);
-      }
-    }
-    // ---- epilogue: the buffer of the last stage becomes the store-transpose scratch once every
-    //      wave has left it (the DMA of the next stage is filling the OTHER buffer meanwhile)
-    asm volatile("s_barrier" ::: "memory");
-    conv_epilogue<TT, MI, NI>(acc, smem + ((s - 1) & 1) * SB + wave * (16 * (NI * 64 + 16)), m0 + wave * 64, p.M, p.Cout,
-                              nt << 6, p.shift, (const typename TT::elem*)p.res, (typename TT::elem*)p.out, p.relu, lane);
-    after_store = full_tile;  // >= 8 epilogue VMEM ops (8 stores [+ 8 residual loads]) are younger than the pending DMA
-    seq = next_seq;
-    if (seq >= ntiles) break;
-  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -637,43 +453,6 @@ extern "C" int frmap_conv_igemm(const void* in, const void* w_packed, const floa
     p.nblocks = ((p.M + BM - 1) / BM) * ntiles;
     const int lds = p.halo_bytes + wbytes;
     return dtype == FRMAP_BF16 ? launch<BF16, 256, 1, 1>(p, lds, st) : launch<F16, 256, 1, 1>(p, lds, st);
-  }
-  // 3x3 stride 1 with a single channel tile whose whole weight set fits beside two halo buffers
-  // (Cin = Cout = 64: ResNet layer1): persistent weights-resident pipelined kernel.
-  if (stride == 1 && ntiles == 1) {
-    static int use_pipe = -1;
-    if (use_pipe < 0) { const char* e = getenv("FRMAP_CONV_PIPE"); use_pipe = e ? atoi(e) : 0; }  // experiment, off by default: slower than the 2-workgroup/CU kernel
-    long long hb1 = (long long)halo_rows_bound(256, Ho, Wo, p.Hp, 1, 3) * p.Wp * 64;
-    hb1 = (hb1 + 1023) & ~1023ll;
-    const long long lds2 = 2 * hb1 + (long long)p.nchunks * wbytes;
-    if (use_pipe && lds2 <= 160 * 1024 && hb1 / 16 <= 10 * 256 && (long long)B * Hi * Wi * Cin < (1ll << 32) - 64) {
-      p.halo_bytes = (int)hb1;
-      p.nblocks = (p.M + 255) / 256;  // total tiles; the grid is persistent
-      static int ncu = 0;
-      if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-               prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-      }
-      const int grid = p.nblocks < ncu ? p.nblocks : ncu;
-      static bool attr[2] = {false, false};
-      const void* kern = dtype == FRMAP_BF16 ? (const void*)conv3x3_pipe_kernel<BF16, true> : (const void*)conv3x3_pipe_kernel<F16, true>;
-      if (!attr[dtype]) {
-        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) {
-          frmap_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
-          return -2;
-        }
-        attr[dtype] = true;
-      }
-      if (dtype == FRMAP_BF16)
-        hipLaunchKernelGGL((conv3x3_pipe_kernel<BF16, true>), dim3(grid), dim3(256), (int)lds2, st, p);
-      else
-        hipLaunchKernelGGL((conv3x3_pipe_kernel<F16, true>), dim3(grid), dim3(256), (int)lds2, st, p);
-      FRMAP_LAUNCH_CHECK();
-      return 0;
-    }
   }
   // 3x3 stride 2 (even input height): row-parity split staging, two workgroups per CU
   if (stride == 2 && Hi % 2 == 0 && p.dbg == 0) {
