@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="faces per GPU per step")
     ap.add_argument("--gallery", type=int, default=36)
-    ap.add_argument("--model", default="cnn", choices=["cnn", "arcface", "baseline", "siamese"])
+    ap.add_argument("--model", default="cnn", choices=["cnn", "arcface", "baseline", "siamese", "hybrid"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -94,7 +94,7 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(2002 + rank)
     x = torch.randn((B, 3, 224, 224), device=dev, dtype=torch.float32, generator=gen)  # resident in HBM
-    need_norm = args.model in ("cnn", "baseline")
+    need_norm = args.model in ("cnn", "baseline", "hybrid")
     total = B * world
 
     def local_step():
@@ -179,7 +179,7 @@ def main():
         xc = x[:nb].cpu()
         gal = gallery.matrix.cpu()
         emb_fn = {"cnn": fo.cnn_embedding, "arcface": fo.arcface_embedding, "baseline": fo.baseline_embedding,
-                  "siamese": fo.siamese_forward_one}[args.model]
+                  "siamese": fo.siamese_forward_one, "hybrid": fo.hybrid_embedding}[args.model]
         best = float("inf")
         with torch.no_grad():
             for rep in range(4):
