@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--gallery", type=int, default=36)
     ap.add_argument("--model", default="cnn", choices=["cnn", "arcface", "baseline", "siamese", "hybrid"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--streams", type=int, default=1, help="split the per-GPU batch over this many HIP streams")
+    ap.add_argument("--graph", type=int, default=0, help="1: replay the step from a captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -97,14 +99,33 @@ def main():
     need_norm = args.model in ("cnn", "baseline", "hybrid")
     total = B * world
 
+    graphed = frmap_amd.GraphedEmbedMatch(model, gallery, x, 1.0, normalize=need_norm, streams=args.streams) if args.graph else None
+    side = [torch.cuda.Stream(device=dev) for _ in range(max(args.streams - 1, 0))]
+    xs = list(x.chunk(args.streams)) if args.streams > 1 else [x]
+
     def local_step():
-        return frmap_amd.embed_and_match(model, x, gallery, 1.0, normalize=need_norm)
+        if graphed is not None:
+            graphed()
+            return graphed.ids(), graphed.dists()
+        if args.streams == 1:
+            return frmap_amd.embed_and_match(model, x, gallery, 1.0, normalize=need_norm)
+        # micro-batches on concurrent streams: one stream's tail waves run beside the other's full waves
+        main = torch.cuda.current_stream()
+        outs = [None] * args.streams
+        for i, st in enumerate(side):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                outs[i + 1] = frmap_amd.embed_and_match(model, xs[i + 1], gallery, 1.0, normalize=need_norm)
+        outs[0] = frmap_amd.embed_and_match(model, xs[0], gallery, 1.0, normalize=need_norm)
+        for st in side:
+            main.wait_stream(st)
+        return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
 
     def step():
         if world == 1:
             return local_step()
         # the match kernel emits the 8-byte (id, distance) records; one all-gather collates them
-        rec = frmap_amd.embed_and_match(model, x, gallery, 1.0, normalize=need_norm, packed=True)
+        rec = graphed() if graphed is not None else frmap_amd.embed_and_match(model, x, gallery, 1.0, normalize=need_norm, packed=True)
         return fdist.gather_packed(rec)
 
     with torch.no_grad():

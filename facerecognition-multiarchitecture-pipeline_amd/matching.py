@@ -112,6 +112,71 @@ def embed_and_match(model, x: torch.Tensor, gallery, thresh: float = REC_THRESH,
     return ids, dist
 
 
+class GraphedEmbedMatch:
+    """The batched embed → (normalise) → match step captured once into a HIP graph and replayed.
+
+    One step is ~30 kernel launches of 5–150 µs; driven from Python each costs ~10 µs of host time,
+    which caps how many concurrent streams can be kept fed.  Capturing the launches (hipGraph via
+    ``torch.cuda.CUDAGraph`` — our kernels are plain launches on the capturing stream) removes the
+    per-launch host cost, and splitting the batch over ``streams`` concurrent branches lets one
+    branch's tail waves run beside another's full waves (at 256 faces the late ResNet layers have
+    only 392–784 tiles for 512 workgroup slots).
+
+    ``x`` is the static input buffer (fp32 NCHW on the device): write the next batch into
+    ``pipeline.x`` (or pass it to ``__call__``, which copies it) and call; the result is the int32
+    ``[B, 2]`` record tensor ``(id-or-unknown, bits(dist))`` — ``ids()`` / ``dists()`` give views.
+    """
+
+    def __init__(self, model, gallery, x: torch.Tensor, thresh: float = REC_THRESH, normalize: bool = False,
+                 streams: int = 1):
+        if not x.is_cuda:
+            raise RuntimeError("GraphedEmbedMatch needs a device-resident input buffer (no CPU fallback)")
+        self.model, self.x, self.thresh, self.normalize = model, x, float(thresh), bool(normalize)
+        self.gallery = _as_gallery(gallery, x.device)
+        self.streams = max(1, min(int(streams), x.shape[0]))
+        self._side = [torch.cuda.Stream(device=x.device) for _ in range(self.streams - 1)]
+        self._xs = list(self.x.chunk(self.streams))
+        warm = torch.cuda.Stream(device=x.device)
+        warm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(warm), torch.no_grad():   # plans, kernel attributes, allocator pools
+            for _ in range(2):
+                self._run()
+        torch.cuda.current_stream().wait_stream(warm)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.records = self._run()
+
+    def _one(self, xs):
+        return embed_and_match(self.model, xs, self.gallery, self.thresh, normalize=self.normalize, packed=True)
+
+    def _run(self):
+        if self.streams == 1:
+            return self._one(self.x)
+        main = torch.cuda.current_stream()
+        outs = [None] * self.streams
+        for i, st in enumerate(self._side):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                outs[i + 1] = self._one(self._xs[i + 1])
+        outs[0] = self._one(self._xs[0])
+        for st in self._side:
+            main.wait_stream(st)
+        return torch.cat(outs, dim=0)
+
+    def __call__(self, x: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if x is not None and x.data_ptr() != self.x.data_ptr():
+            self.x.copy_(x, non_blocking=True)
+        self.graph.replay()
+        return self.records
+
+    def ids(self) -> torch.Tensor:
+        return self.records[:, 0]
+
+    def dists(self) -> torch.Tensor:
+        return self.records.view(torch.float32)[:, 1]
+
+
 # ------------------------------------------------------------------------------------------------
 # persistence (`app.py:67-123`)
 # ------------------------------------------------------------------------------------------------

@@ -190,3 +190,21 @@ def test_eval_step_and_siamese_verify(gold_dir, calibrated_sd):
     d, p = evaluate.siamese_verify(m, x[:4].to(DEV), x[4:8].to(DEV))
     rd, rp = fo.siamese_decision(*fo.siamese_forward(sd, x[:4], x[4:8]))
     assert torch.allclose(d.cpu(), rd, atol=2e-2) and p.cpu().tolist() == rp.tolist()
+
+
+def test_graphed_multistream_pipeline_matches_eager(calibrated_sd):
+    """HIP-graph replay with the batch split over 2 concurrent streams returns exactly what the eager
+    single-stream call returns (same kernels, same per-face arithmetic), and tracks new inputs."""
+    sd = calibrated_sd("cnn")
+    m = _model("cnn", sd, torch.bfloat16)
+    gal = frmap_amd.Gallery([f"id{i}" for i in range(36)], synth.unit_rows(3002, 36, 512), DEV)
+    x = synth.randn(8101, (12, 3, 224, 224), "gx").to(DEV)
+    ids0, d0 = frmap_amd.embed_and_match(m, x, gal, 1.2, normalize=True)
+    pipe = frmap_amd.GraphedEmbedMatch(m, gal, x.clone(), 1.2, normalize=True, streams=2)
+    pipe()
+    assert torch.equal(pipe.ids(), ids0) and torch.equal(pipe.dists(), d0)
+    x2 = synth.randn(8102, (12, 3, 224, 224), "gx2").to(DEV)
+    ids1, d1 = frmap_amd.embed_and_match(m, x2, gal, 1.2, normalize=True)
+    pipe(x2)
+    assert torch.equal(pipe.ids(), ids1) and torch.equal(pipe.dists(), d1)
+    assert not torch.equal(d0, d1)
