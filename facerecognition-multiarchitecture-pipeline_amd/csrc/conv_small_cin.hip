@@ -203,7 +203,7 @@ extern "C" int frmap_conv_small_cin(const void* in_nhwc4, const void* w_packed, 
   const bool first3 = (KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cout == 32);
   FRMAP_REQUIRE(stem7 || first3, "conv_small_cin: unsupported geometry k=%dx%d s=%d p=%d Cout=%d", KH, KW, stride,
                 pad, Cout);
-  FRMAP_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Wi % 2 == 0, "conv_small_cin: bad input size");
+  FRMAP_REQUIRE(B > 0 && Hi > 0 && Wi > 0, "conv_small_cin: bad input size");
   SmallCinParams p;
   p.in = in_nhwc4; p.wpk = w_packed; p.shift = shift; p.out = out;
   p.N = B; p.Hi = Hi; p.Wi = Wi; p.Cout = Cout;

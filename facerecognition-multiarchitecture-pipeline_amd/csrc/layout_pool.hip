@@ -19,9 +19,36 @@ __global__ void pack_input_kernel(const float* __restrict__ x, typename TT::elem
   }
 }
 
+// odd pixel counts per image: one pixel per thread (the float2 path needs 8-byte aligned planes)
+template <typename TT>
+__global__ void pack_input_scalar_kernel(const float* __restrict__ x, typename TT::elem* __restrict__ out, size_t npix,
+                                         size_t HW) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < npix; i += stride) {
+    const size_t n = i / HW, s = i - n * HW;
+    const float* b = x + n * 3 * HW + s;
+    typename TT::elem e[4] = {TT::from_f32(b[0]), TT::from_f32(b[HW]), TT::from_f32(b[2 * HW]), TT::from_f32(0.f)};
+    u32x2_t w;
+    __builtin_memcpy(&w, e, 8);
+    *(u32x2_t*)(out + i * 4) = w;
+  }
+}
+
 extern "C" int frmap_pack_input_nchw_f32(const float* x, void* out, int B, int H, int W, int dtype, void* stream) {
   FRMAP_REQUIRE(x && out, "pack_input: null pointer");
-  FRMAP_REQUIRE(B > 0 && H > 0 && W > 0 && (H * W) % 2 == 0, "pack_input: H*W must be even");
+  FRMAP_REQUIRE(B > 0 && H > 0 && W > 0, "pack_input: empty input");
+  if ((H * W) % 2 != 0) {
+    FRMAP_REQUIRE(dtype == FRMAP_BF16 || dtype == FRMAP_F16, "pack_input: bad dtype");
+    const size_t HW1 = (size_t)H * W, npix = (size_t)B * HW1;
+    const int blocks1 = (int)((npix + 255) / 256 < 16384 ? (npix + 255) / 256 : 16384);
+    if (dtype == FRMAP_BF16)
+      hipLaunchKernelGGL(pack_input_scalar_kernel<BF16>, dim3(blocks1), dim3(256), 0, (hipStream_t)stream, x, (__bf16*)out, npix, HW1);
+    else
+      hipLaunchKernelGGL(pack_input_scalar_kernel<F16>, dim3(blocks1), dim3(256), 0, (hipStream_t)stream, x, (_Float16*)out, npix, HW1);
+    FRMAP_LAUNCH_CHECK();
+    return 0;
+  }
   FRMAP_REQUIRE(dtype == FRMAP_BF16 || dtype == FRMAP_F16, "pack_input: bad dtype");
   const size_t HW = (size_t)H * W, npairs = (size_t)B * HW / 2;
   const int blocks = (int)((npairs + 255) / 256 < 8192 ? (npairs + 255) / 256 : 8192);

@@ -1,0 +1,96 @@
+"""GPU: size-independent properties at BASELINE.json's full per-GPU sizes and edge-case inputs
+(the CPU oracle is too slow there; these checks need no reference):
+  * per-face independence — a face's embedding does not depend on its batch neighbours (eval-mode BN),
+    so any sub-batch reproduces the big batch's rows bit-for-bit;
+  * determinism — two runs are bit-identical;
+  * enrolment round trip — probes matched against a gallery that contains their own embeddings come
+    back with idx == own row and distance sqrt(D)*1e-6 (the eps term of F.pairwise_distance);
+  * sharding — concatenating per-shard results equals the unsharded result (what the multi-GPU
+    driver relies on)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import frmap_amd  # noqa: E402
+from frmap_amd import dist as fdist  # noqa: E402
+from frmap_amd import ops, synth  # noqa: E402
+
+DEV = "cuda"
+
+
+def _arcface(dtype=torch.bfloat16, classes=36):
+    m = frmap_amd.get_model("arcface", classes)
+    m.load_state_dict(synth.synth_state_dict(synth.shapes_of(m), 1004))
+    return m.to(DEV).eval().set_compute_dtype(dtype)
+
+
+def test_full_size_batch_properties():
+    """config 4 per-GPU shape: 1024 faces, 10 000-ID gallery."""
+    m = _arcface()
+    g = torch.Generator(device=DEV); g.manual_seed(2004)
+    x = torch.randn((1024, 3, 224, 224), device=DEV, generator=g)
+    gal = synth.unit_rows(3004, 10000, 512).to(DEV)
+    with torch.no_grad():
+        emb = m(x)
+        emb2 = m(x)
+        assert torch.equal(emb, emb2)                                       # deterministic
+        assert torch.allclose(emb.norm(dim=1), torch.ones(1024, device=DEV), atol=1e-4)
+        for lo, hi in ((0, 1), (100, 117), (1000, 1024), (255, 257)):       # ragged sub-batches, incl. B == 1
+            assert torch.equal(m(x[lo:hi]), emb[lo:hi]), (lo, hi)           # per-face independence, bit-exact
+        gal[torch.arange(0, 10000, 10)[:1000]] = emb[:1000]                 # enrol the first 1000 probes
+        idx, dist = ops.match_top1(emb, gal)
+        assert torch.equal(idx[:1000].cpu(), torch.arange(0, 10000, 10)[:1000].int())
+        assert float((dist[:1000] - math.sqrt(512) * 1e-6).abs().max()) < 3e-6
+        # sharded == unsharded (8 ragged shards)
+        parts = [ops.match_top1(emb[lo:hi], gal) for lo, hi in (fdist.shard_bounds(1024, r, 8) for r in range(8))]
+        assert torch.equal(torch.cat([p[0] for p in parts]), idx) and torch.equal(torch.cat([p[1] for p in parts]), dist)
+        ids, d = frmap_amd.embed_and_match(m, x[:64], frmap_amd.Gallery([str(i) for i in range(10000)], gal, DEV), 0.5)
+        assert torch.equal(ids.cpu(), torch.where(dist[:64].cpu() <= 0.5, idx[:64].cpu(), torch.full((64,), -1, dtype=torch.int32)))
+
+
+@pytest.mark.parametrize("H,W", [(224, 224), (160, 160), (112, 96), (225, 231), (64, 64)])
+def test_input_sizes_and_batch_of_one(H, W):
+    """The reference accepts any input size (adaptive pooling, face_models.py:30,43; input_size is
+    ignored, :18,791).  224-wide inputs take the fused stem, wider ones the unfused path."""
+    m = frmap_amd.get_model("cnn", 36)
+    m.load_state_dict(synth.synth_state_dict(synth.shapes_of(m), 1002))
+    m = m.to(DEV).eval().set_compute_dtype(torch.float16)
+    x = synth.randn(5000 + H, (3, 3, H, W), "sz").to(DEV)
+    with torch.no_grad():
+        e = m.get_embedding(x)
+        assert e.shape == (3, 512) and torch.isfinite(e).all()
+        e1 = m.get_embedding(x[1:2])
+        assert e1.shape == (512,)                                            # the reference's .squeeze()
+        assert torch.equal(e1, e[1])
+        assert m(x).shape == (3, 36)
+
+
+def test_conv_linearity_and_shift():
+    """conv(2x) == 2*conv(x) exactly (power-of-two scaling commutes with bf16/f16 rounding and fp32
+    accumulation) and the fused shift is added after the accumulation."""
+    for dtype in (torch.float16, torch.bfloat16):
+        x = synth.randn(61, (2, 28, 28, 64), "x").to(dtype).to(DEV)
+        w = ops.pack_conv_weight((synth.randn(62, (128, 64, 3, 3), "w") * 0.05).to(DEV), dtype)
+        z = torch.zeros(128, device=DEV)
+        y1 = ops.conv_igemm(x, w, z, 128, 3, 1, 1, False)
+        y2 = ops.conv_igemm(x * 2, w, z, 128, 3, 1, 1, False)
+        big = y1.float().abs() > 1e-3            # below that fp16 is subnormal: fixed spacing, scaling is not exact
+        assert torch.equal(y2[big], (y1 * 2)[big]) and float((y2.float() - 2 * y1.float()).abs().max()) < 1e-6
+        ys = ops.conv_igemm(x, w, z + 1.0, 128, 3, 1, 1, False)
+        assert torch.allclose(ys.float(), y1.float() + 1.0, atol=2e-2, rtol=1e-2)
+
+
+def test_empty_and_degenerate_match_inputs():
+    e = synth.unit_rows(71, 4, 512).to(DEV)
+    idx, dist = ops.match_top1(e, torch.zeros((0, 512), device=DEV))
+    assert idx.cpu().tolist() == [-1] * 4 and torch.isinf(dist).all()
+    one = synth.unit_rows(72, 1, 512).to(DEV)
+    idx, dist = ops.match_top1(e, one)                                     # single-entry gallery
+    assert idx.cpu().tolist() == [0] * 4
+    z = torch.zeros((2, 512), device=DEV)
+    assert torch.equal(ops.l2_normalize(z), z)                             # F.normalize of a zero row is zero, not NaN
+    with pytest.raises(ValueError):
+        ops.match_top1(e, torch.zeros((3, 256), device=DEV))               # dimension mismatch is rejected, not launched
