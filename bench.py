@@ -105,7 +105,13 @@ def main():
     need_norm = args.model in ("cnn", "baseline", "hybrid")
     total = B * world
 
-    graphed = frmap_amd.GraphedEmbedMatch(model, gallery, x, 1.0, normalize=need_norm, streams=args.streams) if args.graph else None
+    graphed, graph_note = None, ""
+    if args.graph:
+        try:
+            graphed = frmap_amd.GraphedEmbedMatch(model, gallery, x, 1.0, normalize=need_norm, streams=args.streams)
+        except Exception as e:  # capture refused (e.g. another thread touched the device): same kernels, eager launches
+            graph_note = f" (graph capture failed: {type(e).__name__}; eager launches)"
+            torch.cuda.synchronize()
     side = [torch.cuda.Stream(device=dev) for _ in range(max(args.streams - 1, 0))]
     xs = list(x.chunk(args.streams)) if args.streams > 1 else [x]
 
@@ -231,8 +237,8 @@ def main():
             "config": {"workload": f"ResNet18 ('{args.model}') embed + L2-normalise + top-1 match, batch {B}/GPU, "
                                    f"{G}-ID gallery, 224x224x3 fp32 NCHW inputs resident in HBM, random-init weights",
                        "global_batch": total, "parallelism": f"dp{world} (faces sharded, 1 all-gather of 8 B/face)",
-                       "execution": (f"HIP graph replay, {args.streams} concurrent micro-batch streams" if args.graph
-                                     else f"eager launches, {args.streams} stream(s)")},
+                       "execution": (f"HIP graph replay, {args.streams} concurrent micro-batch streams" if graphed is not None
+                                     else f"eager launches, {args.streams} stream(s)" + graph_note)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line), flush=True)

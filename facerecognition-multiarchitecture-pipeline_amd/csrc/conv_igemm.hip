@@ -36,6 +36,8 @@ struct ConvParams {
   int nchunks;
   int halo_bytes;
   int nblocks;
+  int ksplit;    // >1: the chunk loop is split over ksplit workgroups per tile, fp32 partials go to `slab`
+  float* slab;   // [ksplit][M][Cout] fp32 partial sums (split-K only)
   int dbg;  // timing ablations only (FRMAP_CONV_DEBUG): 1 = stage chunk 0 only, 2 = skip the MFMA loop
 };
 
@@ -78,9 +80,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     L = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (b >> 3);
   }
   const int ntiles = p.Cout >> 6;
-  const int mt = L / ntiles, nt = L - mt * ntiles;
+  const int kslice = L % p.ksplit;  // split-K: which slice of the chunk loop this workgroup owns
+  const int Lt = L / p.ksplit;
+  const int mt = Lt / ntiles, nt = Lt - mt * ntiles;
   const int m0 = mt * BM;
   const int mlast = min(m0 + BM, p.M) - 1;
+  const int chunk_lo = (int)(((long long)kslice * p.nchunks) / p.ksplit);
+  const int chunk_hi = (int)(((long long)(kslice + 1) * p.nchunks) / p.ksplit);
 
   // origin of this tile in the "virtual padded row stack": padded row index G = n*Hp + iy + pad.
   int n0 = 0, rr0 = 0, nrows = 0;
@@ -175,10 +181,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) wv[t] = *(const u32x4_t*)(wsrc + t * 4096);
   };
-  if (fast) prefetch(0);
+  if (fast) prefetch(chunk_lo);
 
-  for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-    if (chunk > 0) __syncthreads();  // everyone is done reading the previous chunk's LDS images
+  for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
+    if (chunk > chunk_lo) __syncthreads();  // everyone is done reading the previous chunk's LDS images
     if (fast) {
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) *(u32x4_t*)(wl + t * 4096 + tid * 16) = wv[t];
@@ -188,9 +194,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         if (item < nitems) *(u32x4_t*)(halo + px_off<SWZ>(item >> 2, item & 3)) = hv[u];
       }
       __syncthreads();
-      if (chunk + 1 < p.nchunks) prefetch(chunk + 1);  // in flight under the MFMAs below
+      if (chunk + 1 < chunk_hi) prefetch(chunk + 1);  // in flight under the MFMAs below
     } else {
-    if (!(p.dbg == 1 && chunk > 0)) {
+    if (!(p.dbg == 1 && chunk > chunk_lo)) {
     // ---- weights: straight LDS-DMA copy of the pre-packed slab -------------------------------
     {
       const char* wsrc = (const char*)p.wpk + ((size_t)(nt * p.nchunks + chunk) * TAPS) * 4096 + tid * 16;
@@ -267,8 +273,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 
   // ---- epilogue: + shift (+ residual) (ReLU) -> NHWC, whole-line 16-byte stores via an LDS transpose
   __syncthreads();  // every wave is done reading the staged tiles; LDS is free for the transpose
-  conv_epilogue<TT, MI, NI>(acc, smem + wave * (16 * (NI * 64 + 16)), m0 + wave * (BM / 4), p.M, p.Cout, nt << 6,
-                            p.shift, (const typename TT::elem*)p.res, (typename TT::elem*)p.out, p.relu, lane);
+  if (p.ksplit > 1)
+    conv_epilogue_partial<MI, NI>(acc, smem + wave * (16 * (NI * 64 + 16)), m0 + wave * (BM / 4), p.M, p.Cout, nt << 6,
+                                  p.slab + (size_t)kslice * p.M * p.Cout, lane);
+  else
+    conv_epilogue<TT, MI, NI>(acc, smem + wave * (16 * (NI * 64 + 16)), m0 + wave * (BM / 4), p.M, p.Cout, nt << 6,
+                              p.shift, (const typename TT::elem*)p.res, (typename TT::elem*)p.out, p.relu, lane);
 }
 
 // ================================================================================================
@@ -438,6 +448,8 @@ extern "C" int frmap_conv_igemm(const void* in, const void* w_packed, const floa
   p.M = (int)Mll; p.HoWo = Ho * Wo; p.Hp = Hi + 2 * pad; p.Wp = Wi + 2 * pad;
   p.magic_Wp = frmap_magic((uint32_t)p.Wp); p.magic_Hp = frmap_magic((uint32_t)p.Hp);
   p.nchunks = Cin / 32;
+  p.ksplit = 1;
+  p.slab = nullptr;
   {
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("FRMAP_CONV_DEBUG"); dbg = e ? atoi(e) : 0; }
@@ -505,4 +517,85 @@ extern "C" int frmap_conv_igemm(const void* in, const void* w_packed, const floa
              : (stride == 1 ? launch<TT, 128, 3, 1>(p, lds, st) : launch<TT, 128, 3, 2>(p, lds, st)))
   return dtype == FRMAP_BF16 ? FRMAP_DISPATCH(BF16) : FRMAP_DISPATCH(F16);
 #undef FRMAP_DISPATCH
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wide nn.Linear (+ folded BatchNorm1d) (+ReLU/GELU) (+residual) on the MFMA kernel above (1x1 over
+// H = W = 1), with split-K when the output has too few tiles to fill the GPU (SiameseNet fc.1:
+// 256 x 18432 -> 1024 is 16 tiles but 576 channel chunks).  Partials: each K-slice workgroup
+// stores its fp32 tile to its own slab (plain coalesced stores, deterministic), a second kernel
+// sums the slabs and applies shift / residual / activation.
+// ------------------------------------------------------------------------------------------------
+template <typename TT>
+__global__ void splitk_finalize_kernel(const float* __restrict__ slab, int ksplit, const float* __restrict__ shift,
+                                       const typename TT::elem* __restrict__ res, typename TT::elem* __restrict__ out,
+                                       size_t MN, int N, int act) {
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+  for (; i < MN; i += stride) {
+    f32x4_t a = *(const f32x4_t*)(slab + i);
+    for (int s = 1; s < ksplit; ++s) {
+      const f32x4_t b = *(const f32x4_t*)(slab + (size_t)s * MN + i);
+      a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+    }
+    const int n = (int)(i % N);
+    const f32x4_t sh = *(const f32x4_t*)(shift + n);
+    float v[4] = {a[0] + sh[0], a[1] + sh[1], a[2] + sh[2], a[3] + sh[3]};
+    if (res) {
+      float r[4];
+      unpack4<TT>(*(const u32x2_t*)(res + i), r);
+      v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (act == 1) v[e] = fmaxf(v[e], 0.f);
+      else if (act == 2) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));
+    }
+    *(u32x2_t*)(out + i) = pack4<TT>(v[0], v[1], v[2], v[3]);
+  }
+}
+
+static int linear_ksplit(int M, int K, int N) {
+  const int tiles = ((M + 255) / 256) * (N / 64), nchunks = K / 32;
+  int ks = 384 / (tiles > 0 ? tiles : 1);
+  if (ks > nchunks / 4) ks = nchunks / 4;
+  return ks < 2 ? 1 : ks;
+}
+
+extern "C" size_t frmap_linear_mfma_workspace_bytes(int M, int K, int N) {
+  if (M <= 0 || K <= 0 || N <= 0) return 0;
+  const int ks = linear_ksplit(M, K, N);
+  return ks > 1 ? (size_t)ks * M * N * sizeof(float) : 0;
+}
+
+extern "C" int frmap_linear_mfma(const void* x, const void* w_packed, const float* shift, const void* residual, void* out,
+                                 void* workspace, int M, int K, int N, int act, int dtype, void* stream) {
+  FRMAP_REQUIRE(x && w_packed && shift && out, "linear_mfma: null pointer");
+  FRMAP_REQUIRE(M > 0 && K > 0 && K % 32 == 0 && N > 0 && N % 64 == 0, "linear_mfma: need K %% 32 == 0 and N %% 64 == 0 (M=%d K=%d N=%d)", M, K, N);
+  FRMAP_REQUIRE(dtype == FRMAP_BF16 || dtype == FRMAP_F16, "linear_mfma: bad dtype");
+  const int ks = linear_ksplit(M, K, N);
+  if (ks == 1) return frmap_conv_igemm(x, w_packed, shift, residual, out, M, 1, 1, K, N, 1, 1, 0, act, dtype, stream);
+  FRMAP_REQUIRE(workspace, "linear_mfma: workspace required (frmap_linear_mfma_workspace_bytes)");
+  ConvParams p;
+  p.in = x; p.wpk = w_packed; p.shift = shift; p.res = nullptr; p.out = out;
+  p.N = M; p.Hi = 1; p.Wi = 1; p.Cin = K; p.Ho = 1; p.Wo = 1; p.Cout = N;
+  p.stride = 1; p.pad = 0; p.relu = 0;
+  p.M = M; p.HoWo = 1; p.Hp = 1; p.Wp = 1;
+  p.magic_Wp = frmap_magic(1u); p.magic_Hp = frmap_magic(1u);
+  p.nchunks = K / 32; p.ksplit = ks; p.slab = (float*)workspace; p.dbg = 0;
+  p.halo_bytes = 256 * 64;
+  p.nblocks = ((M + 255) / 256) * (N / 64) * ks;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = dtype == FRMAP_BF16 ? launch<BF16, 256, 1, 1>(p, p.halo_bytes + 4096, st) : launch<F16, 256, 1, 1>(p, p.halo_bytes + 4096, st);
+  if (rc) return rc;
+  const size_t MN = (size_t)M * N;
+  const int blocks = (int)((MN / 4 + 255) / 256 < 4096 ? (MN / 4 + 255) / 256 : 4096);
+  if (dtype == FRMAP_BF16)
+    hipLaunchKernelGGL(splitk_finalize_kernel<BF16>, dim3(blocks), dim3(256), 0, st, (const float*)workspace, ks, shift,
+                       (const __bf16*)residual, (__bf16*)out, MN, N, act);
+  else
+    hipLaunchKernelGGL(splitk_finalize_kernel<F16>, dim3(blocks), dim3(256), 0, st, (const float*)workspace, ks, shift,
+                       (const _Float16*)residual, (_Float16*)out, MN, N, act);
+  FRMAP_LAUNCH_CHECK();
+  return 0;
 }

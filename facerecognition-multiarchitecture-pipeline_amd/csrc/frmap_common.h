@@ -141,6 +141,32 @@ __device__ __forceinline__ void conv_epilogue(const f32x4_t (&acc)[MI][NI], char
   }
 }
 
+// split-K variant of the epilogue: the raw fp32 accumulator tile goes to this K-slice's slab
+// ([M][Cout] fp32), transposed through LDS the same way so every store is 16 bytes per lane.
+template <int MI, int NI>
+__device__ __forceinline__ void conv_epilogue_partial(const f32x4_t (&acc)[MI][NI], char* scratch, int m_wave0, int M,
+                                                      int Cout, int co0, float* __restrict__ slab, int lane) {
+  constexpr int PITCH = NI * 64 + 16, PARTS = NI * 2, PER_LANE = PARTS / 4;
+  const int lr = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) *(f32x4_t*)(scratch + lr * PITCH + ni * 64 + g * 16) = acc[mi][ni];
+#pragma unroll
+    for (int j = 0; j < PER_LANE; ++j) {
+      const int idx = j * 64 + lane, prow = idx / PARTS, part = idx % PARTS;
+      const f32x4_t a = *(const f32x4_t*)(scratch + prow * PITCH + part * 32);
+      const f32x4_t b = *(const f32x4_t*)(scratch + prow * PITCH + part * 32 + 16);
+      const int m = m_wave0 + mi * 16 + prow;
+      if (m < M) {
+        float* o = slab + (size_t)m * Cout + co0 + part * 8;
+        *(f32x4_t*)o = a;
+        *(f32x4_t*)(o + 4) = b;
+      }
+    }
+  }
+}
+
 // exact floor(n / d) for n, d < 65536 with magic = ceil(2^32 / d)
 __host__ __device__ inline uint32_t frmap_magic(uint32_t d) {
   return (uint32_t)(((1ull << 32) + d - 1) / d);

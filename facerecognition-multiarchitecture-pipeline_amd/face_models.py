@@ -88,10 +88,7 @@ class _PackedLinearAsConv:
         self.shift = shift.contiguous()
 
     def __call__(self, x2d: torch.Tensor, relu, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-        B, K = x2d.shape
-        res = residual.view(B, 1, 1, self.cout) if residual is not None else None
-        y = ops.conv_igemm(x2d.view(B, 1, 1, K), self.wpk, self.shift, self.cout, 1, 1, 0, relu, res)
-        return y.view(B, self.cout)
+        return ops.linear_mfma(x2d, self.wpk, self.shift, self.cout, relu, residual)
 
 
 # --------------------------------------------------------------------------------------------

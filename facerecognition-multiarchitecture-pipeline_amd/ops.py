@@ -128,6 +128,29 @@ def conv_igemm(x: torch.Tensor, wpk: torch.Tensor, shift: torch.Tensor, Cout: in
     return out
 
 
+def linear_mfma(x2d: torch.Tensor, wpk: torch.Tensor, shift: torch.Tensor, N: int, act=0,
+                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``act(x · Wᵀ + shift [+ residual])`` on the MFMA conv kernel (split-K when the output is small)."""
+    x2d = _dev(x2d, "linear_mfma.x")
+    M, K = x2d.shape
+    out = torch.empty((M, N), dtype=x2d.dtype, device=x2d.device)
+    lib = _lib.load()
+    nbytes = lib.frmap_linear_mfma_workspace_bytes(M, K, N)
+    ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=x2d.device) if nbytes else None
+    rp = 0
+    if residual is not None:
+        residual = _dev(residual, "linear_mfma.residual", x2d.dtype)
+        if tuple(residual.shape) != (M, N):
+            raise ValueError("linear_mfma: residual must be [M, N]")
+        rp = residual.data_ptr()
+    if wpk.numel() != N * K or wpk.dtype != x2d.dtype:
+        raise ValueError("linear_mfma: packed weight does not match N*K / dtype")
+    _lib.check(lib.frmap_linear_mfma(x2d.data_ptr(), _dev(wpk, "wpk").data_ptr(), _dev(shift, "shift", torch.float32).data_ptr(),
+                                     rp, out.data_ptr(), ws.data_ptr() if ws is not None else 0, M, K, N, int(act),
+                                     dt_code(x2d.dtype), _stream()), "linear_mfma")
+    return out
+
+
 def maxpool(x: torch.Tensor, k: int, stride: int, pad: int) -> torch.Tensor:
     x = _dev(x, "maxpool.x")
     B, H, W, Cc = x.shape

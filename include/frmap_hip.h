@@ -103,6 +103,16 @@ int frmap_conv_igemm(const void* in, const void* w_packed, const float* shift, c
                      void* out, int B, int Hi, int Wi, int Cin, int Cout, int K, int stride, int pad,
                      int relu, int dtype, void* stream);
 
+/* Wide Linear (+folded BatchNorm1d) (+ReLU/GELU `act` as above) (+residual) on the same MFMA kernel:
+ *   out[M][N] = act( x[M][K] · Wᵀ + shift [+ residual] ),  x / residual / out in `dtype`, w_packed from
+ *   frmap_pack_conv_weight(W as [N][K][1][1]).  When the output has too few tiles to fill the GPU the K
+ *   loop is split across workgroups (SiameseNet fc.1, src/face_models.py:148: 18432 -> 1024) and
+ *   `workspace` (device, >= frmap_linear_mfma_workspace_bytes(M,K,N) bytes; may be NULL when that is 0)
+ *   holds the fp32 partial slabs. */
+size_t frmap_linear_mfma_workspace_bytes(int M, int K, int N);
+int frmap_linear_mfma(const void* x, const void* w_packed, const float* shift, const void* residual,
+                      void* out, void* workspace, int M, int K, int N, int act, int dtype, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Pools (NHWC, `dtype`).
  *   frmap_maxpool        : nn.MaxPool2d(k, s, p)  — (3,2,1) ResNet stem; (2,2,0) BaselineNet /

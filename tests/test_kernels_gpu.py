@@ -259,6 +259,24 @@ def test_preprocess_and_eval_glue():
     assert torch.allclose(d.cpu(), dref, rtol=1e-6) and same.cpu().tolist() == (dref < 22.6).int().tolist()
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,K,N,act,res", [(256, 18432, 1024, 1, False), (37, 1024, 512, 1, False), (5, 512, 256, 0, True),
+                                           (300, 2048, 512, 2, True)])
+def test_linear_mfma_splitk(dtype, M, K, N, act, res):
+    x = synth.randn(95, (M, K), "x").to(dtype)
+    w = (synth.randn(96, (N, K), "w") / math.sqrt(K)).to(dtype)
+    shift = synth.randn(97, (N,), "b") * 0.1
+    r = synth.randn(98, (M, N), "r").to(dtype) if res else None
+    ref = x.float() @ w.float().t() + shift
+    if res:
+        ref = ref + r.float()
+    ref = F.relu(ref) if act == 1 else (F.gelu(ref) if act == 2 else ref)
+    wpk = ops.pack_conv_weight(w.float().view(N, K, 1, 1).to(DEV), dtype)
+    y = ops.linear_mfma(x.to(DEV), wpk, shift.to(DEV), N, act, r.to(DEV) if res else None).float().cpu()
+    atol, rtol = _tol(dtype)
+    assert torch.allclose(y, ref, atol=atol, rtol=rtol), (y - ref).abs().max()
+
+
 def test_rejections_do_not_launch():
     with pytest.raises(ValueError):
         ops.conv_igemm(torch.zeros(1, 8, 8, 48, device=DEV, dtype=torch.float16),
