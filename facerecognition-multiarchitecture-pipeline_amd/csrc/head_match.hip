@@ -271,16 +271,18 @@ __global__ void match_finalize_kernel(const float* __restrict__ emb, const float
 // Small galleries (the demo's handful of enrolled faces, the 36-ID benchmark gallery): one wave per
 // probe walks the gallery directly with the exact F.pairwise_distance arithmetic — no GEMM
 // expansion, no atomics, one launch.  lane owns dims lane, lane+64, ...
-__global__ void match_small_kernel(const float* __restrict__ emb, const float* __restrict__ gal,
-                                   int32_t* __restrict__ idx_out, float* __restrict__ dist_out,
-                                   int32_t* __restrict__ id_thr_out, int32_t* __restrict__ packed_out, float thresh,
-                                   int B, int G, int D) {
-  const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-  if (b >= B) return;
+__global__ __launch_bounds__(256) void match_small_kernel(const float* __restrict__ emb, const float* __restrict__ gal,
+                                                          int32_t* __restrict__ idx_out, float* __restrict__ dist_out,
+                                                          int32_t* __restrict__ id_thr_out, int32_t* __restrict__ packed_out,
+                                                          float thresh, int B, int G, int D) {
+  // one workgroup per probe; wave w scores gallery rows 8w..8w+7, 8(w+4).. (8 rows per pass so their
+  // loads are independent); the four waves' (best, index) pairs meet in LDS, lowest index wins ties
+  __shared__ float s_best[4];
+  __shared__ int s_idx[4];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float best = INFINITY;
-  int besti = -1;
-  // 8 gallery rows at a time: their loads are independent (64+ in flight), then 8 wave reductions
-  for (int g0 = 0; g0 < G; g0 += 8) {
+  int besti = 0x7FFFFFFF;
+  for (int g0 = wave * 8; g0 < G; g0 += 32) {
     float s2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s2[j] = 0.f;
@@ -298,14 +300,20 @@ __global__ void match_small_kernel(const float* __restrict__ emb, const float* _
       float v = s2[j];
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (g0 + j < G && v < best) { best = v; besti = g0 + j; }  // strict <: the first minimum wins (app.py:60)
+      if (g0 + j < G && v < best) { best = v; besti = g0 + j; }  // strict <: first minimum within this wave's rows
     }
   }
-  if (lane == 0) {
-    const float d = besti >= 0 ? sqrtf(best) : INFINITY;
-    idx_out[b] = besti;
+  if (lane == 0) { s_best[wave] = best; s_idx[wave] = besti; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (s_best[w] < best || (s_best[w] == best && s_idx[w] < besti)) { best = s_best[w]; besti = s_idx[w]; }
+    const bool any = besti != 0x7FFFFFFF;
+    const float d = any ? sqrtf(best) : INFINITY;
+    const int bi = any ? besti : -1;
+    idx_out[b] = bi;
     dist_out[b] = d;
-    const int idt = (besti >= 0 && d <= thresh) ? besti : -1;
+    const int idt = (any && d <= thresh) ? bi : -1;
     if (id_thr_out) id_thr_out[b] = idt;
     if (packed_out) { packed_out[2 * b] = idt; packed_out[2 * b + 1] = __float_as_int(d); }
   }
@@ -420,7 +428,7 @@ extern "C" int frmap_match_top1(const float* emb, const float* gallery, int32_t*
   FRMAP_REQUIRE(G == 0 || gallery, "match_top1: null gallery");
   hipStream_t st = (hipStream_t)stream;
   if (G > 0 && G <= 64) {
-    hipLaunchKernelGGL(match_small_kernel, dim3(waves_blocks(B)), dim3(256), 0, st, emb, gallery, idx_out, dist_out,
+    hipLaunchKernelGGL(match_small_kernel, dim3(B), dim3(256), 0, st, emb, gallery, idx_out, dist_out,
                        id_or_unknown_out, packed_out, thresh, B, G, D);
     FRMAP_LAUNCH_CHECK();
     return 0;

@@ -130,3 +130,21 @@ def test_synth_is_alias_consistent():
     assert torch.equal(sd["backbone.layer2.0.conv1.weight"], sd["features.5.0.conv1.weight"])
     assert torch.equal(sd["backbone.bn1.running_var"], sd["features.1.running_var"])
     m.load_state_dict(sd)
+
+
+def test_missing_extension_fails_loudly(monkeypatch):
+    """No fallback: without the built library every compute entry raises, it does not route elsewhere."""
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libfrmap_hip.so")
+    assert not _lib.lib_available()
+    with pytest.raises(RuntimeError, match="HIP extension not built"):
+        _lib.load()
+
+
+def test_product_package_never_imports_the_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "facerecognition-multiarchitecture-pipeline_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "import oracle" not in src and "from oracle" not in src, fn
