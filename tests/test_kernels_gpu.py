@@ -277,6 +277,35 @@ def test_linear_mfma_splitk(dtype, M, K, N, act, res):
     assert torch.allclose(y, ref, atol=atol, rtol=rtol), (y - ref).abs().max()
 
 
+def test_conv_igemm_random_geometries():
+    """40 seeded random geometries (odd sizes, ragged tiles, every kernel variant: register-prefetch,
+    generic, stride-2 row-parity split and its odd-height fallback, 1x1 gather) against fp32 torch."""
+    rng = np.random.Generator(np.random.PCG64(2024))
+    for case in range(40):
+        dtype = DTYPES[case % 2]
+        k = int(rng.choice([1, 3, 3, 3]))
+        s_ = int(rng.choice([1, 1, 2]))
+        B = int(rng.integers(1, 6))
+        H, W = int(rng.integers(3, 40)), int(rng.integers(3, 40))
+        Cin, Cout = int(rng.choice([32, 64, 96])), int(rng.choice([64, 128, 192]))
+        pad = 1 if k == 3 else 0
+        relu, res = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        x = synth.randn(3000 + case, (B, Cin, H, W), "x").to(dtype)
+        w = (synth.randn(4000 + case, (Cout, Cin, k, k), "w") * math.sqrt(2.0 / (Cin * k * k))).to(dtype)
+        shift = synth.randn(5000 + case, (Cout,), "b") * 0.1
+        ref = F.conv2d(x.float(), w.float(), None, stride=s_, padding=pad) + shift.view(1, -1, 1, 1)
+        r = synth.randn(6000 + case, tuple(ref.shape), "r").to(dtype) if res else None
+        if res:
+            ref = ref + r.float()
+        if relu:
+            ref = F.relu(ref)
+        y = ops.conv_igemm(_nhwc(x).to(DEV), ops.pack_conv_weight(w.float().to(DEV), dtype), shift.to(DEV), Cout, k, s_, pad,
+                           relu, _nhwc(r).to(DEV) if res else None).float().cpu().permute(0, 3, 1, 2)
+        atol, rtol = _tol(dtype)
+        assert y.shape == ref.shape, (case, y.shape, ref.shape)
+        assert torch.allclose(y, ref, atol=atol, rtol=rtol), (case, B, H, W, Cin, Cout, k, s_, float((y - ref).abs().max()))
+
+
 def test_rejections_do_not_launch():
     with pytest.raises(ValueError):
         ops.conv_igemm(torch.zeros(1, 8, 8, 48, device=DEV, dtype=torch.float16),
