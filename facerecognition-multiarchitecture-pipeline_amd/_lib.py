@@ -30,6 +30,7 @@ PROTOTYPES = {
     "frmap_pack_conv_weight_c3": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "frmap_conv_small_cin": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "frmap_stem7x7_maxpool": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "frmap_stem7x7_maxpool2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "frmap_conv_igemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "frmap_linear_mfma_workspace_bytes": (_sz, [_i, _i, _i]),
     "frmap_linear_mfma": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -35,10 +35,17 @@ struct StemPoolParams {
   int halo_bytes;
 };
 
-template <typename TT>
+// POOL3 = true : MaxPool2d(3, 2, 1) (ResNet stem): 7 conv rows -> 3 pooled rows, strips of 16 conv columns
+//                advance by 14 (7 pooled columns each), first conv row/column of a tile is 2*p0 - 1.
+// POOL3 = false: MaxPool2d(2, 2)    (SiameseNet conv.0-3, face_models.py:115-118): 6 conv rows -> 3 pooled
+//                rows, strips of 16 conv columns -> 8 pooled columns, no overlap.
+template <typename TT, bool POOL3>
 __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams p) {
-  constexpr int MI = 7, NI = 4, KSTEPS = 7, KPAD = 224, WPITCH = (KPAD + 8) * 2, PADL = 5, NROWS = 19;
-  constexpr int WLH = 28 * 4 + 10;  // staged row length (pixels) of a 4-strip half tile
+  constexpr int MI = POOL3 ? 7 : 6, NI = 4, KSTEPS = 7, KPAD = 224, WPITCH = (KPAD + 8) * 2;
+  constexpr int PADL = POOL3 ? 5 : 3, NROWS = 2 * (MI - 1) + 7;
+  constexpr int CSTEP = POOL3 ? 14 : 16;       // conv columns a strip advances by
+  constexpr int PPS = POOL3 ? 7 : 8;           // pooled columns per strip
+  constexpr int WLH = 2 * CSTEP * 4 + (POOL3 ? 10 : 8);  // staged row length (pixels) of a 4-strip half tile
   constexpr int NITEMS = NROWS * (WLH / 2);
   constexpr int NIT = (NITEMS + 255) / 256;  // staging items (2 pixels each) per thread
   constexpr int PITCH = NI * 64 + 16;
@@ -62,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
     constexpr int NV = 64 * WPITCH / 16;
     for (int i = tid; i < NV; i += 256) ((u32x4_t*)wl)[i] = src[i];
   }
-  const int pbase0 = (28 * wave + 2 * lr) * 8 + g * 16;
+  const int pbase0 = (2 * CSTEP * wave + 2 * lr) * 8 + g * 16;
   constexpr int rowb = WLH * 8;
   const int woff = lr * WPITCH + g * 16;
   char* scratch = scratch_all + wave * (16 * PITCH);
@@ -75,9 +82,9 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
     const int t2 = tile / p.nhalves;
     const int n = __builtin_amdgcn_readfirstlane(t2 / p.rgroups);
     const int rg = t2 - n * p.rgroups;
-    const int py0 = rg * 3, cr0 = 2 * py0 - 1, ir0 = 2 * cr0 - 3;
+    const int py0 = rg * 3, cr0 = POOL3 ? 2 * py0 - 1 : 2 * py0, ir0 = 2 * cr0 - 3;
     const int strip = half * 4 + wave;
-    const int colbase = 112 * half;  // input-column origin of this half (4 strips x 14 conv columns x stride 2)
+    const int colbase = 2 * CSTEP * 4 * half;  // input-column origin of this half (4 strips x CSTEP conv columns x stride 2)
     // ---- stage 19 input rows x 122 pixels straight from fp32 NCHW (all loads issued, then packed) --
     {
       // per-image buffer descriptor: 32-bit offsets, colour planes via the scalar offset, pixels
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
           for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = TT::mfma(wf[ni], pf[mi], acc[mi][ni]);
       }
       // mask conv positions outside the image (they act as -inf under the max), pool, store
-      const int cc = 14 * strip - 1 + lr;  // this lane's conv column
+      const int cc = CSTEP * strip + lr - (POOL3 ? 1 : 0);  // this lane's conv column
       const bool colv = (unsigned)cc < (unsigned)p.Wc;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
@@ -147,16 +154,22 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
           f32x4_t v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float m = fmaxf(fmaxf(acc[2 * pr][ni][e], acc[2 * pr + 1][ni][e]), acc[2 * pr + 2][ni][e]);  // rows
-            m = fmaxf(m, fmaxf(__shfl_down(m, 1, 16), __shfl_down(m, 2, 16)));                               // columns
+            float m;
+            if (POOL3) {
+              m = fmaxf(fmaxf(acc[2 * pr][ni][e], acc[2 * pr + 1][ni][e]), acc[2 * pr + 2][ni][e]);  // rows
+              m = fmaxf(m, fmaxf(__shfl_down(m, 1, 16), __shfl_down(m, 2, 16)));                       // columns
+            } else {
+              m = fmaxf(acc[2 * pr][ni][e], acc[2 * pr + 1][ni][e]);
+              m = fmaxf(m, __shfl_down(m, 1, 16));
+            }
             v[e] = m;
           }
-          *(f32x4_t*)(scratch + lr * PITCH + ni * 64 + g * 16) = v;  // valid where lr is even and <= 12
+          *(f32x4_t*)(scratch + lr * PITCH + ni * 64 + g * 16) = v;  // valid where lr is even (and <= 12 for POOL3)
         }
-        const int py = py0 + pr, px = 7 * strip + j;
+        const int py = py0 + pr, px = PPS * strip + j;
         const f32x4_t a = *(const f32x4_t*)(scratch + (2 * j) * PITCH + part * 32);
         const f32x4_t b = *(const f32x4_t*)(scratch + (2 * j) * PITCH + part * 32 + 16);
-        if (j < 7 && px < p.Wq && py < p.Hq) {
+        if (j < PPS && px < p.Wq && py < p.Hq) {
           float o[8] = {a[0] + s0[0], a[1] + s0[1], a[2] + s0[2], a[3] + s0[3],
                         b[0] + s1[0], b[1] + s1[1], b[2] + s1[2], b[3] + s1[3]};
 #pragma unroll
@@ -169,59 +182,73 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
   }
 }
 
-extern "C" int frmap_stem7x7_maxpool(const float* x_nchw, const void* w_packed_c3, const float* shift, void* out,
-                                     int B, int Hi, int Wi, int dtype, void* stream) {
-  FRMAP_REQUIRE(x_nchw && w_packed_c3 && shift && out, "stem7x7_maxpool: null pointer");
-  FRMAP_REQUIRE(dtype == FRMAP_BF16 || dtype == FRMAP_F16, "stem7x7_maxpool: bad dtype %d", dtype);
-  FRMAP_REQUIRE(B > 0 && Hi >= 7 && Wi >= 7 && (long long)Hi * Wi * 12 < 0x7FFFFF00ll, "stem7x7_maxpool: bad input size");
+static int stem_launch(const float* x_nchw, const void* w_packed_c3, const float* shift, void* out, int B, int Hi, int Wi,
+                       int pool3, int dtype, void* stream, const char* who) {
+  FRMAP_REQUIRE(x_nchw && w_packed_c3 && shift && out, "%s: null pointer", who);
+  FRMAP_REQUIRE(dtype == FRMAP_BF16 || dtype == FRMAP_F16, "%s: bad dtype %d", who, dtype);
+  FRMAP_REQUIRE(B > 0 && Hi >= 7 && Wi >= 7 && (long long)Hi * Wi * 12 < 0x7FFFFF00ll, "%s: bad input size", who);
   StemPoolParams p;
   p.x = x_nchw; p.wpk = w_packed_c3; p.shift = shift; p.out = out;
   p.N = B; p.Hi = Hi; p.Wi = Wi;
   p.Hc = (Hi + 6 - 7) / 2 + 1; p.Wc = (Wi + 6 - 7) / 2 + 1;
-  p.Hq = (p.Hc + 2 - 3) / 2 + 1; p.Wq = (p.Wc + 2 - 3) / 2 + 1;
-  p.nstrips = (p.Wq + 6) / 7;
-  FRMAP_REQUIRE(p.nstrips <= 8, "stem7x7_maxpool: input wider than 224+ columns (W=%d); use the unfused path", Wi);
+  if (pool3) { p.Hq = (p.Hc + 2 - 3) / 2 + 1; p.Wq = (p.Wc + 2 - 3) / 2 + 1; }
+  else { p.Hq = p.Hc / 2; p.Wq = p.Wc / 2; }
+  FRMAP_REQUIRE(p.Hq > 0 && p.Wq > 0, "%s: input too small", who);
+  const int pps = pool3 ? 7 : 8;
+  p.nstrips = (p.Wq + pps - 1) / pps;
+  FRMAP_REQUIRE(p.nstrips <= 8, "%s: input wider than ~224 columns (W=%d); use the unfused path", who, Wi);
   p.rgroups = (p.Hq + 2) / 3;
   p.nhalves = (p.nstrips + 3) / 4;
-  p.Wl = 28 * 4 + 10;
+  const int cstep = pool3 ? 14 : 16, mi = pool3 ? 7 : 6;
+  p.Wl = 2 * cstep * 4 + (pool3 ? 10 : 8);
   p.magic_Wl2 = frmap_magic((uint32_t)(p.Wl >> 1));
   const long long nb = (long long)B * p.rgroups * p.nhalves;
-  FRMAP_REQUIRE(nb < (1ll << 31), "stem7x7_maxpool: too many tiles");
-  const int hb = (19 * (p.Wl / 2) * 16 + 1023) & ~1023;
+  FRMAP_REQUIRE(nb < (1ll << 31), "%s: too many tiles", who);
+  const int nrows = 2 * (mi - 1) + 7;
+  const int hb = (nrows * (p.Wl / 2) * 16 + 1023) & ~1023;
   p.halo_bytes = hb;
   const int wbytes = 64 * 232 * 2;
   const int scratch = 4 * 16 * (4 * 64 + 16);
   const int lds = hb + wbytes + scratch;
-  int ncu = 256;
-  {
-    static int cached = 0;
-    if (!cached) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-        cached = prop.multiProcessorCount;
-      else
-        cached = 256;
-    }
-    ncu = cached;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+              ? prop.multiProcessorCount : 256;
   }
   // persistent: two 4-wave workgroups per CU walk the tiles (one stages while the other computes)
   const unsigned grid = (unsigned)(nb < 2ll * ncu ? nb : 2ll * ncu);
   hipStream_t st = (hipStream_t)stream;
-  static bool attr[2] = {false, false};
-  const void* kern = dtype == FRMAP_BF16 ? (const void*)stem_pool_kernel<BF16> : (const void*)stem_pool_kernel<F16>;
-  if (!attr[dtype]) {
+  static bool attr[4] = {false, false, false, false};
+  const int ai = dtype * 2 + (pool3 ? 1 : 0);
+  const void* kern = dtype == FRMAP_BF16 ? (pool3 ? (const void*)stem_pool_kernel<BF16, true> : (const void*)stem_pool_kernel<BF16, false>)
+                                         : (pool3 ? (const void*)stem_pool_kernel<F16, true> : (const void*)stem_pool_kernel<F16, false>);
+  if (!attr[ai]) {
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       frmap_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
       return -2;
     }
-    attr[dtype] = true;
+    attr[ai] = true;
   }
-  if (dtype == FRMAP_BF16)
-    hipLaunchKernelGGL(stem_pool_kernel<BF16>, dim3(grid), dim3(256), lds, st, p);
-  else
-    hipLaunchKernelGGL(stem_pool_kernel<F16>, dim3(grid), dim3(256), lds, st, p);
+  if (dtype == FRMAP_BF16) {
+    if (pool3) hipLaunchKernelGGL((stem_pool_kernel<BF16, true>), dim3(grid), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((stem_pool_kernel<BF16, false>), dim3(grid), dim3(256), lds, st, p);
+  } else {
+    if (pool3) hipLaunchKernelGGL((stem_pool_kernel<F16, true>), dim3(grid), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((stem_pool_kernel<F16, false>), dim3(grid), dim3(256), lds, st, p);
+  }
   FRMAP_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int frmap_stem7x7_maxpool(const float* x_nchw, const void* w_packed_c3, const float* shift, void* out,
+                                     int B, int Hi, int Wi, int dtype, void* stream) {
+  return stem_launch(x_nchw, w_packed_c3, shift, out, B, Hi, Wi, 1, dtype, stream, "stem7x7_maxpool");
+}
+
+extern "C" int frmap_stem7x7_maxpool2(const float* x_nchw, const void* w_packed_c3, const float* shift, void* out,
+                                      int B, int Hi, int Wi, int dtype, void* stream) {
+  return stem_launch(x_nchw, w_packed_c3, shift, out, B, Hi, Wi, 0, dtype, stream, "stem7x7_maxpool2");
 }

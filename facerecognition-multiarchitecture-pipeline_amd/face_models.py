@@ -337,8 +337,13 @@ class SiameseNet(_HipModule):
         p = self._get_plan()
         batch_size = x.size(0)
         self.debug_shapes["input"] = x.shape
-        x = ops.pack_input(x, self.compute_dtype)
-        for conv, pool in p["convs"]:
+        convs = p["convs"]
+        if ((x.shape[3] + 6 - 7) // 2 + 1) // 2 <= 64:   # fused conv.0-3: 7x7 conv + bias + BN + ReLU + MaxPool2d(2,2)
+            x = ops.stem7x7_maxpool(x, convs[0][0].wpk, convs[0][0].shift, self.compute_dtype, pool3=False)
+            convs = convs[1:]
+        else:
+            x = ops.pack_input(x, self.compute_dtype)
+        for conv, pool in convs:
             x = conv(x, relu=True)
             if pool:
                 x = ops.maxpool(x, 2, 2, 0)

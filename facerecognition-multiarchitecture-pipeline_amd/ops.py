@@ -90,15 +90,21 @@ def stem_pool_dims(H: int, W: int):
     return (Hc + 2 - 3) // 2 + 1, (Wc + 2 - 3) // 2 + 1
 
 
-def stem7x7_maxpool(x: torch.Tensor, wpk: torch.Tensor, shift: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
-    """fp32 NCHW -> conv7x7 s2 + shift + ReLU -> maxpool 3x3 s2 p1 -> NHWC B×Hq×Wq×64 (``dtype``)."""
+def stem7x7_maxpool(x: torch.Tensor, wpk: torch.Tensor, shift: torch.Tensor, dtype: torch.dtype,
+                    pool3: bool = True) -> torch.Tensor:
+    """fp32 NCHW -> conv7x7 s2 + shift + ReLU -> maxpool (3x3 s2 p1 if ``pool3`` else 2x2 s2) -> NHWC
+    B×Hq×Wq×64 (``dtype``)."""
     x = _dev(x, "stem7x7_maxpool.x", torch.float32)
     B, C, H, W = x.shape
     if C != 3:
         raise ValueError("stem7x7_maxpool: expected 3 input channels")
-    Hq, Wq = stem_pool_dims(H, W)
+    if pool3:
+        Hq, Wq = stem_pool_dims(H, W)
+    else:
+        Hq, Wq = ((H + 6 - 7) // 2 + 1) // 2, ((W + 6 - 7) // 2 + 1) // 2
     out = torch.empty((B, Hq, Wq, 64), dtype=dtype, device=x.device)
-    _lib.check(_lib.load().frmap_stem7x7_maxpool(x.data_ptr(), _dev(wpk, "wpk", dtype).data_ptr(),
+    fn = _lib.load().frmap_stem7x7_maxpool if pool3 else _lib.load().frmap_stem7x7_maxpool2
+    _lib.check(fn(x.data_ptr(), _dev(wpk, "wpk", dtype).data_ptr(),
                                                  _dev(shift, "shift", torch.float32).data_ptr(), out.data_ptr(),
                                                  B, H, W, dt_code(dtype), _stream()), "stem7x7_maxpool")
     return out

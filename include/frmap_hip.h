@@ -83,6 +83,10 @@ int frmap_conv_small_cin(const void* in_nhwc4, const void* w_packed, const float
  * ------------------------------------------------------------------------------------------- */
 int frmap_stem7x7_maxpool(const float* x_nchw, const void* w_packed_c3, const float* shift, void* out,
                           int B, int Hi, int Wi, int dtype, void* stream);
+/* Same fusion with MaxPool2d(2, 2): SiameseNet conv.0-3 (conv 7x7 s2 p3 + bias + BN + ReLU + pool,
+ * src/face_models.py:115-118); out = B×(Hc/2)×(Wc/2)×64. */
+int frmap_stem7x7_maxpool2(const float* x_nchw, const void* w_packed_c3, const float* shift, void* out,
+                           int B, int Hi, int Wi, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution, NHWC, MFMA 16x16x32 (bf16 / f16), fused epilogue

@@ -93,6 +93,21 @@ def test_fused_stem_maxpool(dtype, B, H, W):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W", [(3, 224, 224), (2, 100, 84), (2, 61, 37)])
+def test_fused_stem_maxpool2x2(dtype, B, H, W):
+    x = synth.randn(28, (B, 3, H, W), "x")
+    w = (synth.randn(29, (64, 3, 7, 7), "w") * math.sqrt(2.0 / 147)).to(dtype)
+    shift = synth.randn(30, (64,), "b") * 0.3
+    conv = F.relu(F.conv2d(x.to(dtype).float(), w.float(), None, stride=2, padding=3) + shift.view(1, -1, 1, 1))
+    ref = F.max_pool2d(conv.to(dtype).float(), 2, 2)
+    y = ops.stem7x7_maxpool(x.to(DEV), ops.pack_conv_weight_c3(w.float().to(DEV), dtype), shift.to(DEV), dtype, pool3=False)
+    y = y.float().cpu().permute(0, 3, 1, 2)
+    atol, rtol = _tol(dtype)
+    assert y.shape == ref.shape, (y.shape, ref.shape)
+    assert torch.allclose(y, ref, atol=atol, rtol=rtol), (y - ref).abs().max()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_pools(dtype):
     x = synth.randn(31, (3, 64, 30, 22), "x").to(dtype)
     xd = _nhwc(x).to(DEV)
