@@ -392,6 +392,131 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_split_kernel(const ConvParam
                             (const typename TT::elem*)p.res, (typename TT::elem*)p.out, p.relu, lane);
 }
 
+// ================================================================================================
+// 1x1 convolutions and wide Linear layers: a plain gather-GEMM with WIDE stages.
+//
+// The generic kernel's 32-channel chunk gives a 1x1 conv only 16 MFMAs per wave between barriers.
+// Here a stage is CKS x 32 channels (CKS = 4: 128): 256 gathered pixels x 128 channels (64 KB) +
+// 64 x 128 weights (16 KB) per stage, 64 MFMAs per wave per stage, both operands of the next stage
+// prefetched into registers under the current stage's MFMAs.  Split-K as in frmap_linear_mfma.
+// ================================================================================================
+template <typename TT, int CKS>
+__global__ __launch_bounds__(256, 2) void conv1x1_kernel(const ConvParams p) {
+  constexpr int BM = 256, MI = 4, NI = 4, NIT = BM * 4 / 256;
+  using vec8 = typename TT::vec8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;                     // [CKS][256 px][64 B]
+  char* wl = smem + CKS * BM * 64;       // [CKS][64 cout][64 B]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, g = lane >> 4;
+  const int L = xcd_remap_fwd(blockIdx.x, p.nblocks);
+  const int ntiles = p.Cout >> 6;
+  const int kslice = L % p.ksplit, Lt = L / p.ksplit;
+  const int mt = Lt / ntiles, nt = Lt - mt * ntiles;
+  const int m0 = mt * BM;
+  const int st_lo = (int)(((long long)kslice * p.nchunks) / p.ksplit);   // nchunks = stages of CKS*32 channels
+  const int st_hi = (int)(((long long)(kslice + 1) * p.nchunks) / p.ksplit);
+
+  const typename TT::elem* inp = (const typename TT::elem*)p.in;
+  size_t gsrc[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int px = (it * 256 + tid) >> 2;
+    const int m = min(m0 + px, p.M - 1);
+    const int n = m / p.HoWo, rem = m - n * p.HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    gsrc[it] = (((size_t)n * p.Hi + (size_t)(oy * p.stride)) * p.Wi + (size_t)(ox * p.stride)) * p.Cin + (size_t)((tid & 3) * 8);
+  }
+  int poff[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) poff[mi] = px_off<1>(wave * 64 + mi * 16 + lr, g);
+  const int woff = (lr << 6) + ((g ^ (((lr >> 2) & 1) << 1)) << 4);
+  const char* wbase = (const char*)p.wpk + (size_t)nt * p.nchunks * CKS * 4096 + tid * 16;
+
+  u32x4_t hv[CKS][NIT], wv[CKS];
+  auto prefetch = [&](int stg) {
+#pragma unroll
+    for (int sc = 0; sc < CKS; ++sc) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) hv[sc][it] = *(const u32x4_t*)(inp + gsrc[it] + (size_t)(stg * CKS + sc) * 32);
+      wv[sc] = *(const u32x4_t*)(wbase + (size_t)(stg * CKS + sc) * 4096);
+    }
+  };
+  f32x4_t acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  if (st_lo < st_hi) prefetch(st_lo);
+  for (int stg = st_lo; stg < st_hi; ++stg) {
+    if (stg > st_lo) __syncthreads();
+#pragma unroll
+    for (int sc = 0; sc < CKS; ++sc) {
+      *(u32x4_t*)(wl + sc * 4096 + tid * 16) = wv[sc];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+        *(u32x4_t*)(halo + sc * (BM * 64) + px_off<1>((it * 256 + tid) >> 2, tid & 3)) = hv[sc][it];
+    }
+    __syncthreads();
+    if (stg + 1 < st_hi) prefetch(stg + 1);
+#pragma unroll
+    for (int sc = 0; sc < CKS; ++sc) {
+      vec8 wf[NI], pf[MI];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wf[ni] = *(const vec8*)(wl + sc * 4096 + ni * 1024 + woff);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) pf[mi] = *(const vec8*)(halo + sc * (BM * 64) + poff[mi]);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = TT::mfma(wf[ni], pf[mi], acc[mi][ni]);
+    }
+  }
+  __syncthreads();
+  if (p.ksplit > 1)
+    conv_epilogue_partial<MI, NI>(acc, smem + wave * (16 * (NI * 64 + 16)), m0 + wave * 64, p.M, p.Cout, nt << 6,
+                                  p.slab + (size_t)kslice * p.M * p.Cout, lane);
+  else
+    conv_epilogue<TT, MI, NI>(acc, smem + wave * (16 * (NI * 64 + 16)), m0 + wave * 64, p.M, p.Cout, nt << 6, p.shift,
+                              (const typename TT::elem*)p.res, (typename TT::elem*)p.out, p.relu, lane);
+}
+
+template <typename TT, int CKS>
+static int launch_1x1(const ConvParams& p, hipStream_t st) {
+  auto kern = conv1x1_kernel<TT, CKS>;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      frmap_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return -2;
+    }
+    attr = true;
+  }
+  int lds = CKS * (256 * 64 + 4096);
+  const int scratch = 4 * 16 * (4 * 64 + 16);
+  if (lds < scratch) lds = scratch;
+  hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), lds, st, p);
+  FRMAP_LAUNCH_CHECK();
+  return 0;
+}
+
+// p.nchunks must hold Cin/32 on entry; picks the stage width and rewrites it in stages
+static int dispatch_1x1(ConvParams& p, int dtype, hipStream_t st) {
+  const int c32 = p.Cin / 32;
+  if (c32 % 4 == 0) {
+    p.nchunks = c32 / 4;
+    return dtype == FRMAP_BF16 ? launch_1x1<BF16, 4>(p, st) : launch_1x1<F16, 4>(p, st);
+  }
+  if (c32 % 2 == 0) {
+    p.nchunks = c32 / 2;
+    return dtype == FRMAP_BF16 ? launch_1x1<BF16, 2>(p, st) : launch_1x1<F16, 2>(p, st);
+  }
+  p.nchunks = c32;
+  return dtype == FRMAP_BF16 ? launch_1x1<BF16, 1>(p, st) : launch_1x1<F16, 1>(p, st);
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -463,6 +588,7 @@ extern "C" int frmap_conv_igemm(const void* in, const void* w_packed, const floa
     const int BM = 256;
     p.halo_bytes = BM * 64;
     p.nblocks = ((p.M + BM - 1) / BM) * ntiles;
+    if (p.dbg == 0 && Cin >= 128) return dispatch_1x1(p, dtype, st);  // wide stages pay once there are several of them
     const int lds = p.halo_bytes + wbytes;
     return dtype == FRMAP_BF16 ? launch<BF16, 256, 1, 1>(p, lds, st) : launch<F16, 256, 1, 1>(p, lds, st);
   }
@@ -586,15 +712,23 @@ extern "C" int frmap_linear_mfma(const void* x, const void* w_packed, const floa
   p.halo_bytes = 256 * 64;
   p.nblocks = ((M + 255) / 256) * (N / 64) * ks;
   hipStream_t st = (hipStream_t)stream;
-  int rc = dtype == FRMAP_BF16 ? launch<BF16, 256, 1, 1>(p, p.halo_bytes + 4096, st) : launch<F16, 256, 1, 1>(p, p.halo_bytes + 4096, st);
+  // K slices are counted in kernel stages (up to 128 channels each)
+  {
+    const int c32 = K / 32, cks = c32 % 4 == 0 ? 4 : (c32 % 2 == 0 ? 2 : 1);
+    if (p.ksplit > c32 / cks) p.ksplit = c32 / cks;
+    p.nblocks = ((M + 255) / 256) * (N / 64) * p.ksplit;
+  }
+  if (p.ksplit < 2) return frmap_conv_igemm(x, w_packed, shift, residual, out, M, 1, 1, K, N, 1, 1, 0, act, dtype, stream);
+  int rc = dispatch_1x1(p, dtype, st);
   if (rc) return rc;
+  const int ks_used = p.ksplit;
   const size_t MN = (size_t)M * N;
   const int blocks = (int)((MN / 4 + 255) / 256 < 4096 ? (MN / 4 + 255) / 256 : 4096);
   if (dtype == FRMAP_BF16)
-    hipLaunchKernelGGL(splitk_finalize_kernel<BF16>, dim3(blocks), dim3(256), 0, st, (const float*)workspace, ks, shift,
+    hipLaunchKernelGGL(splitk_finalize_kernel<BF16>, dim3(blocks), dim3(256), 0, st, (const float*)workspace, ks_used, shift,
                        (const __bf16*)residual, (__bf16*)out, MN, N, act);
   else
-    hipLaunchKernelGGL(splitk_finalize_kernel<F16>, dim3(blocks), dim3(256), 0, st, (const float*)workspace, ks, shift,
+    hipLaunchKernelGGL(splitk_finalize_kernel<F16>, dim3(blocks), dim3(256), 0, st, (const float*)workspace, ks_used, shift,
                        (const _Float16*)residual, (_Float16*)out, MN, N, act);
   FRMAP_LAUNCH_CHECK();
   return 0;
