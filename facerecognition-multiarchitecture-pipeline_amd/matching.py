@@ -78,6 +78,26 @@ def match_batch(emb: torch.Tensor, gallery: Gallery) -> Tuple[torch.Tensor, torc
     return ops.match_top1(emb.to(torch.float32), gallery.matrix)
 
 
+def get_embedding(face_img, model):
+    """`app.py:32-48`: BGR uint8 crop → RGB → Resize((160,160)) → ToTensor → Normalize(0.5, 0.5) →
+    ``model(x)`` on the model's device under ``no_grad``; ``None`` for an empty crop or on ANY
+    exception (the reference swallows them, `:46-48`).  The resize is PIL's (host), the
+    uint8 → normalised-float step and the model run on the GPU."""
+    if face_img is None or getattr(face_img, "size", 0) == 0:
+        return None
+    try:
+        from PIL import Image
+        rgb = np.ascontiguousarray(np.asarray(face_img)[:, :, ::-1])
+        pil = Image.fromarray(rgb).resize((160, 160), Image.BILINEAR)
+        dev = next(model.parameters()).device
+        u8 = torch.from_numpy(np.asarray(pil, np.uint8)).unsqueeze(0).to(dev)
+        x = ops.normalize_u8(u8, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))[0]
+        with torch.no_grad():
+            return model(x)
+    except Exception:
+        return None
+
+
 def compare_faces(emb, refs, thresh):
     """`app.py:50-64` on the GPU."""
     if emb is None or refs is None or len(refs) == 0:

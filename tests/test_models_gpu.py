@@ -208,3 +208,21 @@ def test_graphed_multistream_pipeline_matches_eager(calibrated_sd):
     pipe(x2)
     assert torch.equal(pipe.ids(), ids1) and torch.equal(pipe.dists(), d1)
     assert not torch.equal(d0, d1)
+
+
+def test_app_get_embedding_mirror(calibrated_sd):
+    """`app.py:32-48`: BGR crop -> 160x160 -> [-1,1] -> model; None on empty input or any failure."""
+    from PIL import Image
+    sd = calibrated_sd("arcface")
+    m = _model("arcface", sd, torch.float16)
+    g = np.random.Generator(np.random.PCG64(77))
+    bgr = g.integers(0, 256, (97, 83, 3), dtype=np.uint8)
+    emb = frmap_amd.get_embedding(bgr, m)
+    assert emb.shape == (1, 512) and emb.is_cuda
+    pil = Image.fromarray(np.ascontiguousarray(bgr[:, :, ::-1])).resize((160, 160), Image.BILINEAR)
+    x = (torch.from_numpy(np.asarray(pil)).permute(2, 0, 1).float().div(255) - 0.5) / 0.5
+    ref = fo.arcface_embedding(sd, x.unsqueeze(0))
+    assert float(1 - F.cosine_similarity(emb.cpu(), ref, dim=1)) < 1e-3
+    assert frmap_amd.get_embedding(None, m) is None
+    assert frmap_amd.get_embedding(np.zeros((0, 0, 3), np.uint8), m) is None
+    assert frmap_amd.get_embedding(np.zeros((5, 5), np.uint8), m) is None          # wrong rank -> exception -> None
