@@ -90,7 +90,7 @@ def get_embedding(face_img, model):
         rgb = np.ascontiguousarray(np.asarray(face_img)[:, :, ::-1])
         pil = Image.fromarray(rgb).resize((160, 160), Image.BILINEAR)
         dev = next(model.parameters()).device
-        u8 = torch.from_numpy(np.asarray(pil, np.uint8)).unsqueeze(0).to(dev)
+        u8 = torch.from_numpy(np.array(pil, np.uint8)).unsqueeze(0).to(dev)
         x = ops.normalize_u8(u8, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))[0]
         with torch.no_grad():
             return model(x)
