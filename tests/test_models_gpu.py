@@ -220,7 +220,7 @@ def test_app_get_embedding_mirror(calibrated_sd):
     emb = frmap_amd.get_embedding(bgr, m)
     assert emb.shape == (1, 512) and emb.is_cuda
     pil = Image.fromarray(np.ascontiguousarray(bgr[:, :, ::-1])).resize((160, 160), Image.BILINEAR)
-    x = (torch.from_numpy(np.asarray(pil)).permute(2, 0, 1).float().div(255) - 0.5) / 0.5
+    x = (torch.from_numpy(np.array(pil)).permute(2, 0, 1).float().div(255) - 0.5) / 0.5
     ref = fo.arcface_embedding(sd, x.unsqueeze(0))
     assert float(1 - F.cosine_similarity(emb.cpu(), ref, dim=1)) < 1e-3
     assert frmap_amd.get_embedding(None, m) is None
