@@ -1,5 +1,5 @@
 // Token-side kernels of the hybrid CNN-Transformer (gfx950): positional add + LayerNorm, 4-head
-// self-attention over the 49 tokens of one face, token mean + final LayerNorm.
+// self-attention over the 49 tokens of one face (QK^T and PV on MFMA), token mean + final LayerNorm.
 //
 // Replaces, for eval mode, the non-GEMM parts of TransformerBlock.forward and HybridNet.get_embedding
 // (/root/reference/src/face_models.py:636-648, 705-721): nn.LayerNorm (eps 1e-5), the
@@ -82,62 +82,119 @@ extern "C" int frmap_add_pos_layernorm(const void* x, const float* pos, const fl
 }
 
 // ------------------------------------------------------------------------------------------------
-// Multi-head self-attention over L <= 64 tokens, head dim 128.  qkv: [B][L][3D] (q | k | v, each D =
-// H*128 wide, as nn.MultiheadAttention's in_proj produces); out: [B][L][D].  One workgroup per
-// (face, head): K and V of the head sit in LDS as fp32 (pitch 129 -> conflict-free), each wave
-// takes query rows round-robin; lane j scores key j, softmax is a wave reduction, P stays in LDS,
-// and each lane then produces two of the 128 output dims.  fp32 math throughout.
+// Multi-head self-attention over L <= 64 tokens, head dim 128, on the matrix cores.
+// qkv: [B][L][3D] (q | k | v, each D = H*128 wide, as nn.MultiheadAttention's in_proj produces);
+// out: [B][L][D].  One workgroup (4 waves) per (face, head); L is padded to 64 with zero rows.
+//   S = Q K^T   : MFMA 16x16x32, wave w owns query rows 16w..16w+15 (4 key tiles x 4 k-steps);
+//                 both operands are K-contiguous rows of the LDS images Q[64][128], K[64][128].
+//   softmax     : a lane holds 4 query rows x 4 key tiles of S (fp32); the key axis lies across
+//                 the 16 lanes of its lane group -> in-register + 4 xor-shuffles; keys >= L masked.
+//   O = P V     : P (rounded to the storage dtype) goes through a wave-private LDS tile to become
+//                 the A operand; V is staged TRANSPOSED (Vt[128][64]) so the B operand is K-contiguous;
+//                 8 value tiles x 2 k-steps per wave.  fp32 accumulation throughout.
+//   store       : O tile -> wave-private LDS -> 16-byte whole-line stores.
 // ------------------------------------------------------------------------------------------------
 template <typename TT>
 __global__ __launch_bounds__(256) void mha_tokens_kernel(const typename TT::elem* __restrict__ qkv,
                                                          typename TT::elem* __restrict__ out, int L, int D, int H) {
-  constexpr int DH = 128, PITCH = DH + 1;
+  constexpr int DH = 128, LP = 64;
+  constexpr int QP = (DH + 8) * 2;   // byte pitch of a Q / K row (272 B: 16-byte aligned, staggers banks)
+  constexpr int VP = (LP + 8) * 2;   // byte pitch of a Vt row   (144 B)
+  constexpr int OP = (DH + 8) * 2;   // byte pitch of an O row   (272 B)
+  using vec8 = typename TT::vec8;
+  using elem = typename TT::elem;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* Ks = (float*)smem;             // [L][PITCH]
-  float* Vs = Ks + 64 * PITCH;          // [L][PITCH]
-  float* Qs = Vs + 64 * PITCH;          // [4 waves][DH]
-  float* Ps = Qs + 4 * DH;              // [4 waves][64]
+  char* Qs = smem;                    // [64][QP]
+  char* Ks = Qs + LP * QP;            // [64][QP]
+  char* Vt = Ks + LP * QP;            // [128][VP]
+  char* Ps = Vt + DH * VP;            // [4 waves][16][VP]   probabilities of the wave's 16 query rows
+  char* Os = Ps + 4 * 16 * VP;        // [4 waves][16][OP]
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const typename TT::elem* base = qkv + (size_t)b * L * 3 * D;
-  for (int i = tid; i < L * DH; i += 256) {
-    const int j = i / DH, d = i - j * DH;
-    Ks[j * PITCH + d] = TT::to_f32(base[(size_t)j * 3 * D + D + h * DH + d]);
-    Vs[j * PITCH + d] = TT::to_f32(base[(size_t)j * 3 * D + 2 * D + h * DH + d]);
+  const int lr = lane & 15, g = lane >> 4;
+  const elem* base = qkv + (size_t)b * L * 3 * D + h * DH;
+
+  // ---- stage Q, K (row-major) and V (transposed); rows >= L are zero ---------------------------
+  for (int i = tid; i < LP * (DH / 8); i += 256) {
+    const int row = i >> 4, c8 = i & 15;  // 16 x 16-byte pieces per 128-wide row
+    u32x4_t q = {0u, 0u, 0u, 0u}, k = q, v = q;
+    if (row < L) {
+      const elem* src = base + (size_t)row * 3 * D + c8 * 8;
+      q = *(const u32x4_t*)(src);
+      k = *(const u32x4_t*)(src + D);
+      v = *(const u32x4_t*)(src + 2 * D);
+    }
+    *(u32x4_t*)(Qs + row * QP + c8 * 16) = q;
+    *(u32x4_t*)(Ks + row * QP + c8 * 16) = k;
+    elem ve[8];
+    __builtin_memcpy(ve, &v, 16);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) *(elem*)(Vt + (c8 * 8 + e) * VP + row * 2) = ve[e];
   }
   __syncthreads();
+
+  // ---- S = Q K^T for this wave's 16 query rows ------------------------------------------------
+  f32x4_t sacc[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) sacc[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < DH / 32; ++ks) {
+    const vec8 qa = *(const vec8*)(Qs + (wave * 16 + lr) * QP + ks * 64 + g * 16);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const vec8 kb = *(const vec8*)(Ks + (nt * 16 + lr) * QP + ks * 64 + g * 16);
+      sacc[nt] = TT::mfma(qa, kb, sacc[nt]);  // D[row = query (g*4+r)][col = key (nt*16+lr)]
+    }
+  }
+  // ---- softmax over keys: row r of this lane = query wave*16 + g*4 + r ---------------------------
   const float scale = rsqrtf((float)DH);
-  float* q = Qs + wave * DH;
-  float* pr = Ps + wave * 64;
-  for (int i = wave; i < L; i += 4) {
-    q[lane] = TT::to_f32(base[(size_t)i * 3 * D + h * DH + lane]) * scale;
-    q[lane + 64] = TT::to_f32(base[(size_t)i * 3 * D + h * DH + lane + 64]) * scale;
-    // scores: lane j <-> key j   (same-wave LDS ops are ordered; no barrier needed)
-    float sc = -INFINITY;
-    if (lane < L) {
-      float a = 0.f;
-#pragma unroll 8
-      for (int d = 0; d < DH; ++d) a += q[d] * Ks[lane * PITCH + d];
-      sc = a;
-    }
-    float mx = sc;
+  char* pw = Ps + wave * 16 * VP;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    float e = lane < L ? __expf(sc - mx) : 0.f;
-    float sum = e;
+  for (int r = 0; r < 4; ++r) {
+    float v[4], mx = -INFINITY;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-    pr[lane] = e / sum;
-    // out[i][d] = sum_j P[j] V[j][d], two dims per lane
-    float o0 = 0.f, o1 = 0.f;
-    for (int j = 0; j < L; ++j) {
-      const float pj = pr[j];
-      o0 += pj * Vs[j * PITCH + lane];
-      o1 += pj * Vs[j * PITCH + lane + 64];
+    for (int nt = 0; nt < 4; ++nt) {
+      v[nt] = (nt * 16 + lr) < L ? sacc[nt][r] * scale : -INFINITY;
+      mx = fmaxf(mx, v[nt]);
     }
-    typename TT::elem* dst = out + ((size_t)b * L + i) * D + h * DH;
-    dst[lane] = TT::from_f32(o0);
-    dst[lane + 64] = TT::from_f32(o1);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+    float sum = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      v[nt] = __expf(v[nt] - mx);
+      sum += v[nt];
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) *(elem*)(pw + (g * 4 + r) * VP + (nt * 16 + lr) * 2) = TT::from_f32(v[nt] * inv);
+  }
+  // ---- O = P V  (wave-private P tile; same-wave LDS ops are ordered) ---------------------------
+  f32x4_t oacc[8];
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) oacc[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < LP / 32; ++ks) {
+    const vec8 pa = *(const vec8*)(pw + lr * VP + ks * 64 + g * 16);
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+      const vec8 vb = *(const vec8*)(Vt + (nt * 16 + lr) * VP + ks * 64 + g * 16);
+      oacc[nt] = TT::mfma(pa, vb, oacc[nt]);  // D[row = query (g*4+r)][col = d (nt*16+lr)]
+    }
+  }
+  // ---- store through a wave-private tile: 16 rows x 256 B, 16 bytes per lane per pass ------------
+  char* ow = Os + wave * 16 * OP;
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *(elem*)(ow + (g * 4 + r) * OP + (nt * 16 + lr) * 2) = TT::from_f32(oacc[nt][r]);
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int idx = pass * 64 + lane, row = idx >> 4, c8 = idx & 15;
+    const int i = wave * 16 + row;
+    if (i < L) *(u32x4_t*)(out + ((size_t)b * L + i) * D + h * DH + c8 * 8) = *(const u32x4_t*)(ow + row * OP + c8 * 16);
   }
 }
 
@@ -146,7 +203,7 @@ extern "C" int frmap_mha_tokens(const void* qkv, void* out, int B, int L, int D,
   FRMAP_REQUIRE(B > 0 && L > 0 && L <= 64 && H > 0 && D == H * 128, "mha_tokens: need L <= 64 and head dim 128 (D=%d H=%d L=%d)", D, H, L);
   FRMAP_REQUIRE(dtype == FRMAP_BF16 || dtype == FRMAP_F16, "mha_tokens: bad dtype");
   FRMAP_REQUIRE((long long)B * H < (1ll << 31), "mha_tokens: too many heads");
-  const int lds = (2 * 64 * 129 + 4 * 128 + 4 * 64) * 4;
+  const int lds = 2 * 64 * 272 + 128 * 144 + 4 * 16 * 144 + 4 * 16 * 272;
   hipStream_t st = (hipStream_t)stream;
   static bool attr[2] = {false, false};
   const void* kern = dtype == FRMAP_BF16 ? (const void*)mha_tokens_kernel<BF16> : (const void*)mha_tokens_kernel<F16>;
