@@ -11,7 +11,7 @@ gallery").  With N GPUs every rank runs the same per-GPU batch (weak scaling: fa
 embarrassingly) and one RCCL all-gather collates the (id, distance) pairs each step.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     — the dominant kernel (conv_igemm_kernel<BF16,256,3,1,true>: the 3×3 stride-1 implicit-GEMM
+  roofline     — the dominant kernel (conv3x3_fast_kernel<BF16>: the 3×3 stride-1 implicit-GEMM
                  convolutions, 13 launches per full-batch forward): algorithmic FLOPs per launch ÷ its
                  average launch duration, measured with HIP events on the launch stream in a separate
                  instrumented pass after the timed region — standalone eager launches at the full per-GPU
@@ -36,7 +36,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/fp16, MI355X_MICROARCH.md
-DOMINANT = "conv_igemm_kernel<BF16, 256, 3, 1, true>"
+DOMINANT = "conv3x3_fast_kernel<BF16>"
 
 
 def _pmc_traffic(kernel, args, dtype):

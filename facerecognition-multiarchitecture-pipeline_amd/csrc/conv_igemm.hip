@@ -56,7 +56,7 @@ __device__ __forceinline__ int px_off(int q, int slot) {
   return ((q >> 2) << 8) + (((((q & 3) << 2) | slot) ^ (((q >> 2) & 3) << 1)) << 4);
 }
 
-template <typename TT, int BM, int KS, int SWZ, bool FAST>
+template <typename TT, int BM, int KS, int SWZ>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
   constexpr int MI = BM / 64;
   constexpr int NI = 4;
@@ -100,8 +100,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   }
 
   // per-lane LDS byte offsets of the B-operand (pixel) fragments, one per (pixel group, tap)
-  int offs[FAST ? 1 : MI][FAST ? 1 : TAPS];
-  int qbase[MI];
+  int offs[MI][TAPS];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = min(m0 + wave * (BM / 4) + mi * 16 + lr, p.M - 1);
@@ -115,11 +114,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
       const int ox = rem - oy * p.Wo;
       qb = ((n - n0) * p.Hp + oy * p.stride - rr0) * p.Wp + ox * p.stride;
     }
-    qbase[mi] = qb;
-    if (!FAST) {
 #pragma unroll
-      for (int t = 0; t < TAPS; ++t) offs[FAST ? 0 : mi][FAST ? 0 : t] = px_off<SWZ>(qb + (t / KS) * p.Wp + (t % KS), g);
-    }
+    for (int t = 0; t < TAPS; ++t) offs[mi][t] = px_off<SWZ>(qb + (t / KS) * p.Wp + (t % KS), g);
   }
   // A-operand (weights) fragment offset inside one tap's 4 KB image
   const int woff = (lr << 6) + ((g ^ (((lr >> 2) & 1) << 1)) << 4);
@@ -149,53 +145,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   const typename TT::elem* inp = (const typename TT::elem*)p.in;
   const int nitems = nrows * p.Wp * 4;
 
-  // ---- register-prefetch path (3x3, halo <= 10 items per thread: every stride-1 ResNet/Siamese layer):
-  // the NEXT chunk's halo pixels and weight slab are loaded into registers while the MFMAs of the
-  // current chunk run (issue early / write late); the stage phase is then only LDS writes.
-  constexpr int NB = 10;
-  constexpr bool fast = FAST;  // host guarantees KS == 3 and nitems <= 256 * NB
-  unsigned soff[NB];
-  u32x4_t hv[NB], wv[TAPS];
-  if (fast) {
-#pragma unroll
-    for (int u = 0; u < NB; ++u) {
-      const int item = u * 256 + tid;
-      const int px = item >> 2, cg = item & 3;
-      const int r = (int)fast_div((uint32_t)px, p.magic_Wp);
-      const int c = px - r * p.Wp;
-      const int rr = rr0 + r;
-      const int dn = (int)fast_div((uint32_t)rr, p.magic_Hp);
-      const int iy = rr - dn * p.Hp - p.pad, ix = c - p.pad, n = n0 + dn;
-      const bool ok = item < nitems && n < p.N && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-      soff[u] = ok ? (unsigned)(((n - n0) * p.Hi + iy) * p.Wi + ix) * (unsigned)p.Cin + (unsigned)(cg * 8) : 0xFFFFFFFFu;
-    }
-  }
-  const typename TT::elem* inp0 = inp + (size_t)n0 * p.Hi * p.Wi * p.Cin;  // image n0: tile-relative offsets fit 32 bits
-  auto prefetch = [&](int chunk) {
-#pragma unroll
-    for (int u = 0; u < NB; ++u) {
-      const typename TT::elem* a = soff[u] != 0xFFFFFFFFu ? inp0 + soff[u] + chunk * 32 : (const typename TT::elem*)g_zero_page;
-      hv[u] = *(const u32x4_t*)a;  // unconditional: padding reads the zero page
-    }
-    const char* wsrc = (const char*)p.wpk + ((size_t)(nt * p.nchunks + chunk) * TAPS) * 4096 + tid * 16;
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t) wv[t] = *(const u32x4_t*)(wsrc + t * 4096);
-  };
-  if (fast) prefetch(chunk_lo);
-
   for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
     if (chunk > chunk_lo) __syncthreads();  // everyone is done reading the previous chunk's LDS images
-    if (fast) {
-#pragma unroll
-      for (int t = 0; t < TAPS; ++t) *(u32x4_t*)(wl + t * 4096 + tid * 16) = wv[t];
-#pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        const int item = u * 256 + tid;
-        if (item < nitems) *(u32x4_t*)(halo + px_off<SWZ>(item >> 2, item & 3)) = hv[u];
-      }
-      __syncthreads();
-      if (chunk + 1 < chunk_hi) prefetch(chunk + 1);  // in flight under the MFMAs below
-    } else {
     if (!(p.dbg == 1 && chunk > chunk_lo)) {
     // ---- weights: straight LDS-DMA copy of the pre-packed slab -------------------------------
     {
@@ -252,7 +203,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     }
     __syncthreads();  // (also drains the LDS-DMA: hipcc emits vmcnt(0) ahead of the barrier)
     if (p.dbg == 2) continue;
-    }
 
     // ---- KS*KS k-steps of 32 channels out of LDS -----------------------------------------------
 #pragma unroll
@@ -262,8 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
       for (int ni = 0; ni < NI; ++ni) wf[ni] = *(const vec8*)(wl + t * 4096 + ni * 1024 + woff);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
-        pf[mi] = *(const vec8*)(halo + (FAST ? px_off<SWZ>(qbase[mi] + (t / KS) * p.Wp + (t % KS), g)
-                                             : offs[FAST ? 0 : mi][FAST ? 0 : t]));
+        pf[mi] = *(const vec8*)(halo + offs[mi][t]);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -279,6 +228,158 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   else
     conv_epilogue<TT, MI, NI>(acc, smem + wave * (16 * (NI * 64 + 16)), m0 + wave * (BM / 4), p.M, p.Cout, nt << 6,
                               p.shift, (const typename TT::elem*)p.res, (typename TT::elem*)p.out, p.relu, lane);
+}
+
+// ================================================================================================
+// 3x3 stride-1 convolutions whose halo is <= 10 16-byte pieces per thread (every stride-1 layer of the
+// ResNet / Siamese / Baseline trunks): register-prefetch, software-pipelined.
+//
+//  * Two workgroups per CU, one tile each.  The NEXT 32-channel chunk's halo pixels and weight slab
+//    (19 pieces per thread) are loaded into registers while the current chunk's MFMAs run, and
+//    written to LDS at the next chunk boundary (issue early / write late).
+//  * Loads are raw buffer loads: padding pixels carry an out-of-range offset and read 0; an EMPTY
+//    descriptor turns the prefetch slots of the last chunk into no-ops without a second code path.
+//    (A persistent variant that also prefetched the workgroup's next tile measured no faster - a
+//    tile's prologue is already covered by the co-resident workgroup - and lost the hardware's
+//    dynamic tile placement: layer3 80 us vs 76 us.)
+//  * The 19 loads ride between the MFMAs (one after every ~2 groups of 4): issued as one burst they
+//    stall the wave ~1400 cycles on the 64 B/clk vector-memory path.
+//  * Fragment pipeline pinned with sched_barriers: pixel fragments of tap t+1 are requested before
+//    tap t's MFMAs, weight fragment ni of tap t+1 right after tap t's MFMAs on it (left alone the
+//    scheduler sinks every ds_read to just before its use and each group of 4 MFMAs waits out an
+//    LDS round trip).  The 36 per-tap pixel addresses are recomputed (3 VALU ops, under the MFMAs).
+// ================================================================================================
+template <typename TT>
+__global__ __launch_bounds__(256, 2) void conv3x3_fast_kernel(const ConvParams p) {
+  constexpr int MI = 4, NI = 4, TAPS = 9, NB = 10, NL = NB + TAPS, NG = TAPS * NI;
+  using vec8 = typename TT::vec8;
+  using elem = typename TT::elem;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;
+  char* wl = smem + p.halo_bytes;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, g = lane >> 4;
+  const int ntiles = p.Cout >> 6;
+  const int wslab = p.nchunks * (TAPS * 4096);
+  const int woff = (lr << 6) + ((g ^ (((lr >> 2) & 1) << 1)) << 4);
+  const elem* inp = (const elem*)p.in;
+  const size_t total_el = (size_t)p.N * p.Hi * p.Wi * p.Cin;
+
+  // ---- load-side state: the tile whose staging data is being fetched
+  unsigned soff[NB];
+  u32x4_t hv[NB], wv[TAPS];
+  int l_nitems = 0, l_n0 = 0, l_rr0 = 0, in_records = 0;
+  const elem* in_base = inp;
+  const char* w_base = (const char*)p.wpk;
+  auto setup_load = [&](int L) {
+    const int mt = L / ntiles, nt = L - mt * ntiles;
+    const int m0 = mt << 8, mlast = min(m0 + 256, p.M) - 1;
+    const int n0 = m0 / p.HoWo, oy0 = (m0 - n0 * p.HoWo) / p.Wo;
+    const int n1 = mlast / p.HoWo, oy1 = (mlast - n1 * p.HoWo) / p.Wo;
+    const int nrows = (n1 - n0) * p.Hp + oy1 - oy0 + 3;
+    l_nitems = nrows * p.Wp * 4; l_n0 = n0; l_rr0 = oy0;
+    const size_t base_el = (size_t)n0 * p.Hi * p.Wi * p.Cin;  // image n0: tile-relative byte offsets fit 31 bits
+    const size_t rem = (total_el - base_el) * sizeof(elem);
+    in_base = inp + base_el;
+    in_records = (int)(rem < 0x7FFFFFFFull ? rem : 0x7FFFFFFFull);
+    w_base = (const char*)p.wpk + (size_t)nt * wslab;
+    const int tl = tid;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int item = u * 256 + tl;
+      const int px = item >> 2, cg = item & 3;
+      const int r = (int)fast_div((uint32_t)px, p.magic_Wp);
+      const int c = px - r * p.Wp;
+      const int rr = oy0 + r;
+      const int dn = (int)fast_div((uint32_t)rr, p.magic_Hp);
+      const int iy = rr - dn * p.Hp - 1, ix = c - 1, n = n0 + dn;
+      const bool ok = item < l_nitems && n < p.N && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      soff[u] = ok ? ((unsigned)((dn * p.Hi + iy) * p.Wi + ix) * (unsigned)p.Cin + (unsigned)(cg * 8)) * (unsigned)sizeof(elem)
+                   : 0xFFFFFF00u;
+    }
+  };
+  __amdgpu_buffer_rsrc_t rs_in, rs_w;
+  auto set_rsrc = [&](bool live) {
+    rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in_base, (short)0, live ? in_records : 0, 0x00020000);
+    rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)w_base, (short)0, live ? wslab : 0, 0x00020000);
+  };
+  // piece j of a stage: j < NB halo pixels, then the 9 weight taps (already in LDS-image order)
+  auto prefetch1 = [&](int chunk, int j) {
+    if (j < NB) hv[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)soff[j], chunk * 64, 0);
+    else wv[j - NB] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, tid * 16, (chunk * TAPS + (j - NB)) * 4096, 0);
+  };
+
+  const int L = xcd_remap_fwd(blockIdx.x, gridDim.x);
+  setup_load(L);
+  set_rsrc(true);
+#pragma unroll
+  for (int j = 0; j < NL; ++j) prefetch1(0, j);
+
+  {
+    const int mt = L / ntiles, nt = L - mt * ntiles;
+    const int m0 = mt << 8;
+    int A[MI];  // (pixel index in the halo image) * 64 + k-group * 16, before the tap offset and the swizzle
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = min(m0 + wave * 64 + mi * 16 + lr, p.M - 1);
+      const int n = m / p.HoWo, rem = m - n * p.HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      A[mi] = ((((n - l_n0) * p.Hp + oy - l_rr0) * p.Wp + ox) << 6) | (g << 4);
+    }
+    f32x4_t acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+      __syncthreads();  // everyone is done with the previous stage's LDS images / the epilogue scratch
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) *(u32x4_t*)(wl + t * 4096 + tid * 16) = wv[t];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int item = u * 256 + tid;
+        if (item < l_nitems) *(u32x4_t*)(halo + px_off<1>(item >> 2, item & 3)) = hv[u];
+      }
+      __syncthreads();
+      // what the prefetch slots of this stage fetch
+      const int pchunk = chunk + 1;
+      set_rsrc(pchunk < p.nchunks);
+
+      vec8 wf[NI], pf[2][MI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) asm volatile("" : "+v"(A[mi]));  // keep the per-tap addresses out of registers
+      auto paddr = [&](int mi, int t) {
+        const int at = A[mi] + (((t / 3) * p.Wp + (t % 3)) << 6);
+        return at ^ ((at >> 3) & 32);
+      };
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wf[ni] = *(const vec8*)(wl + ni * 1024 + woff);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) pf[0][mi] = *(const vec8*)(halo + paddr(mi, 0));
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        if (t + 1 < TAPS) {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) pf[(t + 1) & 1][mi] = *(const vec8*)(halo + paddr(mi, t + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = TT::mfma(wf[ni], pf[t & 1][mi], acc[mi][ni]);
+          if (t + 1 < TAPS) wf[ni] = *(const vec8*)(wl + (t + 1) * 4096 + ni * 1024 + woff);
+          const int k = t * NI + ni;
+          if ((k + 1) * NL / NG != k * NL / NG) prefetch1(pchunk, k * NL / NG);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    // ---- epilogue: + shift (+ residual) (activation) -> NHWC, whole-line 16-byte stores via an LDS transpose
+    __syncthreads();  // every wave is done reading the staged tiles; LDS is free for the transpose
+    conv_epilogue<TT, MI, NI>(acc, smem + wave * (16 * (NI * 64 + 16)), m0 + wave * 64, p.M, p.Cout, nt << 6, p.shift,
+                              (const elem*)p.res, (elem*)p.out, p.relu, lane);
+  }
 }
 
 // ================================================================================================
@@ -530,9 +631,9 @@ static int halo_rows_bound(int BM, int Ho, int Wo, int Hp, int stride, int KS) {
   return gdiff + KS;
 }
 
-template <typename TT, int BM, int KS, int SWZ, bool FAST = false>
+template <typename TT, int BM, int KS, int SWZ>
 static int launch(const ConvParams& p, int lds_bytes, hipStream_t st) {
-  auto kern = conv_igemm_kernel<TT, BM, KS, SWZ, FAST>;
+  auto kern = conv_igemm_kernel<TT, BM, KS, SWZ>;
   static int attr_set = 0;
   if (attr_set < lds_bytes) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -634,12 +735,32 @@ extern "C" int frmap_conv_igemm(const void* in, const void* w_packed, const floa
   p.halo_bytes = (int)hb;
   p.nblocks = ((p.M + BM - 1) / BM) * ntiles;
   const int lds = p.halo_bytes + wbytes;
-  // register-prefetch variant when the whole halo is <= 10 items per thread (and no ablation flag)
-  const bool fastk = BM == 256 && stride == 1 && p.dbg == 0 && hb / 16 <= 10 * 256 &&
-                     (long long)(256 / (Ho * Wo) + 3) * Hi * Wi * Cin < (1ll << 31);
+  // register-prefetch persistent kernel when the whole halo is <= 10 pieces per thread (and no ablation flag)
+  const bool fastk = BM == 256 && stride == 1 && p.dbg == 0 && hb / 16 <= 10 * 256 && lds <= 80 * 1024 &&
+                     (long long)(256 / (Ho * Wo) + 3) * Hi * Wi * Cin * 2 < (1ll << 31);
+  if (fastk) {
+    const int grid = p.nblocks;
+    const void* kern = dtype == FRMAP_BF16 ? (const void*)conv3x3_fast_kernel<BF16> : (const void*)conv3x3_fast_kernel<F16>;
+    static bool attr[2] = {false, false};
+    if (!attr[dtype]) {
+      hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) {
+        frmap_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return -2;
+      }
+      attr[dtype] = true;
+    }
+    const int scratch = 4 * 16 * (4 * 64 + 16);
+    const int ldsf = lds < scratch ? scratch : lds;
+    if (dtype == FRMAP_BF16)
+      hipLaunchKernelGGL(conv3x3_fast_kernel<BF16>, dim3(grid), dim3(256), ldsf, st, p);
+    else
+      hipLaunchKernelGGL(conv3x3_fast_kernel<F16>, dim3(grid), dim3(256), ldsf, st, p);
+    FRMAP_LAUNCH_CHECK();
+    return 0;
+  }
 #define FRMAP_DISPATCH(TT)                                                                   \
-  (fastk ? launch<TT, 256, 3, 1, true>(p, lds, st)                                           \
-   : BM == 256 ? (stride == 1 ? launch<TT, 256, 3, 1>(p, lds, st) : launch<TT, 256, 3, 2>(p, lds, st)) \
+  (BM == 256 ? (stride == 1 ? launch<TT, 256, 3, 1>(p, lds, st) : launch<TT, 256, 3, 2>(p, lds, st)) \
              : (stride == 1 ? launch<TT, 128, 3, 1>(p, lds, st) : launch<TT, 128, 3, 2>(p, lds, st)))
   return dtype == FRMAP_BF16 ? FRMAP_DISPATCH(BF16) : FRMAP_DISPATCH(F16);
 #undef FRMAP_DISPATCH
