@@ -493,6 +493,161 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_split_kernel(const ConvParam
                             (const typename TT::elem*)p.res, (typename TT::elem*)p.out, p.relu, lane);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same row-parity split with the software pipeline of conv3x3_fast_kernel: a stage is (chunk,
+// parity plane); the next stage's plane pixels (<= 12 pieces per thread) and its 6 or 3 weight taps
+// are buffer-loaded into registers between the current stage's MFMAs and written to LDS at the stage
+// boundary.  Used when a plane is <= 12 pieces per thread (all three ResNet stride-2 convs).
+// ------------------------------------------------------------------------------------------------
+template <typename TT>
+__global__ __launch_bounds__(256, 2) void conv3x3s2_fast_kernel(const ConvParams p) {
+  constexpr int MI = 4, NI = 4, NB = 12, NW = 6, NL = NB + NW;
+  using vec8 = typename TT::vec8;
+  using elem = typename TT::elem;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;
+  char* wl = smem + p.halo_bytes;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, g = lane >> 4;
+  const int L = xcd_remap_fwd(blockIdx.x, p.nblocks);
+  const int ntiles = p.Cout >> 6;
+  const int mt = L / ntiles, nt = L - mt * ntiles;
+  const int m0 = mt << 8, mlast = min(m0 + 256, p.M) - 1;
+  const int Hh = p.Hp >> 1;  // padded rows per image and parity
+  const int n0 = m0 / p.HoWo, oy0 = (m0 - n0 * p.HoWo) / p.Wo;
+  const int n1 = mlast / p.HoWo, oy1 = (mlast - n1 * p.HoWo) / p.Wo;
+  const int span = (n1 - n0) * Hh + oy1 - oy0;  // last pixel's row index within a parity plane
+  const int rr0 = 2 * oy0;                       // padded row of the tile's first even row
+  const int woff = (lr << 6) + ((g ^ (((lr >> 2) & 1) << 1)) << 4);
+  const elem* inp = (const elem*)p.in;
+
+  int A[MI];  // linear byte address (pixel * 64 + k-group * 16) in a plane image, before tap offset and swizzle
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = min(m0 + wave * 64 + mi * 16 + lr, p.M - 1);
+    const int n = m / p.HoWo, rem = m - n * p.HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    A[mi] = ((((n - n0) * Hh + oy - oy0) * p.Wp + 2 * ox) << 6) | (g << 4);
+  }
+
+  // Source byte offsets (relative to image n0) of this thread's pieces.  Plane row r of the even plane is
+  // input row 2j-1 of its image, of the odd plane row 2j: the odd-plane piece is always one input row
+  // below the even-plane piece, so one offset per piece + a validity bit per plane suffices
+  // (invalid -> out-of-range offset -> the load returns the zero padding).
+  unsigned soff[NB];
+  unsigned vmask = 0;  // bit u: even-plane piece u is in the image; bit 16+u: odd-plane piece
+  const int nitems0 = (span + 2) * p.Wp * 4, nitems1 = (span + 1) * p.Wp * 4;
+  const unsigned rowbytes = (unsigned)p.Wi * (unsigned)p.Cin * (unsigned)sizeof(elem);
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {
+    const int item = u * 256 + tid;
+    const int px = item >> 2, cg = item & 3;
+    const int r = (int)fast_div((uint32_t)px, p.magic_Wp);
+    const int c = px - r * p.Wp;
+    const int rr = rr0 + 2 * r;  // even padded row in the stack of images
+    const int dn = (int)fast_div((uint32_t)rr, p.magic_Hp);
+    const int iy = rr - dn * p.Hp - 1, ix = c - 1, n = n0 + dn;
+    const bool colok = n < p.N && (unsigned)ix < (unsigned)p.Wi;
+    soff[u] = ((unsigned)((dn * p.Hi + iy) * p.Wi + ix) * (unsigned)p.Cin + (unsigned)(cg * 8)) * (unsigned)sizeof(elem);
+    if (colok && item < nitems0 && iy >= 0) vmask |= 1u << u;
+    if (colok && item < nitems1 && iy + 1 < p.Hi) vmask |= 1u << (16 + u);
+  }
+  const size_t base_el = (size_t)n0 * p.Hi * p.Wi * p.Cin;
+  const size_t rem_b = ((size_t)p.N * p.Hi * p.Wi * p.Cin - base_el) * sizeof(elem);
+  const int in_records = (int)(rem_b < 0x7FFFFFFFull ? rem_b : 0x7FFFFFFFull);
+  const int wslab = p.nchunks * (9 * 4096);
+  const char* w_base = (const char*)p.wpk + (size_t)nt * wslab;
+  __amdgpu_buffer_rsrc_t rs_in, rs_w;
+  auto set_rsrc = [&](bool live) {
+    rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)(inp + base_el), (short)0, live ? in_records : 0, 0x00020000);
+    rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)w_base, (short)0, live ? wslab : 0, 0x00020000);
+  };
+  u32x4_t hv[NB], wv[NW];
+  // piece j of stage (chunk, par): j < NB plane pixels, then the stage's weight taps (even plane: kh 0 and 2; odd: kh 1)
+  auto prefetch1 = [&](int chunk, int par, int j) {
+    if (j < NB) {
+      const unsigned o = (vmask >> (par * 16 + j)) & 1u ? soff[j] + (par ? rowbytes : 0u) : 0xFFFFFF00u;
+      hv[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)o, chunk * 64, 0);
+    } else {
+      const int t = j - NB;
+      if (t < (par ? 3 : 6)) {
+        const int tap = par ? 3 + t : (t < 3 ? t : t + 3);
+        wv[t] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, tid * 16, (chunk * 9 + tap) * 4096, 0);
+      }
+    }
+  };
+
+  f32x4_t acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  set_rsrc(true);
+#pragma unroll
+  for (int j = 0; j < NL; ++j) prefetch1(0, 0, j);
+
+  for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {  // 0: even padded rows, taps kh in {0,2};  1: odd rows, kh = 1
+      const int ntap = par ? 3 : 6;
+      __syncthreads();  // everyone is done reading the previous stage's LDS images
+#pragma unroll
+      for (int t = 0; t < NW; ++t)
+        if (t < ntap) *(u32x4_t*)(wl + t * 4096 + tid * 16) = wv[t];
+      int tl = tid;
+      asm volatile("" : "+v"(tl));  // recompute the 12 LDS destinations per stage instead of keeping them live
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int item = u * 256 + tl;
+        if (item < (par ? nitems1 : nitems0)) *(u32x4_t*)(halo + px_off<2>(item >> 2, item & 3)) = hv[u];
+      }
+      __syncthreads();
+      // next stage: the odd plane of this chunk, or the even plane of the next chunk
+      const int pc = par ? chunk + 1 : chunk, pp = par ^ 1;
+      set_rsrc(pc < p.nchunks);
+      asm volatile("" : "+v"(vmask));  // select each piece's offset at its load, not 24 hoisted copies
+
+      vec8 wf[NI], pf[2][MI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) asm volatile("" : "+v"(A[mi]));  // per-tap addresses: 3 VALU ops each, not 36 registers
+      auto paddr = [&](int mi, int t) {
+        const int dq = par ? t : (t / 3) * p.Wp + (t % 3);  // even plane: kh=0 -> row +0, kh=2 -> row +1
+        const int at = A[mi] + (dq << 6);
+        return at ^ ((at >> 3) & 0x60);  // == px_off<2>
+      };
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wf[ni] = *(const vec8*)(wl + ni * 1024 + woff);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) pf[0][mi] = *(const vec8*)(halo + paddr(mi, 0));
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        if (t < ntap) {
+          if (t + 1 < ntap) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) pf[(t + 1) & 1][mi] = *(const vec8*)(halo + paddr(mi, t + 1));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = TT::mfma(wf[ni], pf[t & 1][mi], acc[mi][ni]);
+            if (t + 1 < ntap) wf[ni] = *(const vec8*)(wl + (t + 1) * 4096 + ni * 1024 + woff);
+            const int k = t * NI + ni, ng = ntap * NI;
+#pragma unroll
+            for (int j = 0; j < NL; ++j)
+              if (j >= k * NL / ng && j < (k + 1) * NL / ng) prefetch1(pc, pp, j);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  conv_epilogue<TT, MI, NI>(acc, smem + wave * (16 * (NI * 64 + 16)), m0 + wave * 64, p.M, p.Cout, nt << 6, p.shift,
+                            (const elem*)p.res, (elem*)p.out, p.relu, lane);
+}
+
 // ================================================================================================
 // 1x1 convolutions and wide Linear layers: a plain gather-GEMM with WIDE stages.
 //
@@ -714,7 +869,25 @@ extern "C" int frmap_conv_igemm(const void* in, const void* w_packed, const floa
         }
         attr[dtype] = true;
       }
-      if (dtype == FRMAP_BF16)
+      static int s2fast = -1;
+      if (s2fast < 0) { const char* e = getenv("FRMAP_CONV_S2FAST"); s2fast = e ? atoi(e) : 1; }
+      const bool fast2 = s2fast && hbs / 16 <= 12 * 256 && (long long)(256 / (Ho * Wo) + 3) * Hi * Wi * Cin * 2 < (1ll << 31);
+      if (fast2) {
+        static bool attr2[2] = {false, false};
+        const void* k2 = dtype == FRMAP_BF16 ? (const void*)conv3x3s2_fast_kernel<BF16> : (const void*)conv3x3s2_fast_kernel<F16>;
+        if (!attr2[dtype]) {
+          hipError_t e = hipFuncSetAttribute(k2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          if (e != hipSuccess) {
+            frmap_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return -2;
+          }
+          attr2[dtype] = true;
+        }
+        if (dtype == FRMAP_BF16)
+          hipLaunchKernelGGL(conv3x3s2_fast_kernel<BF16>, dim3(p.nblocks), dim3(256), lds, st, p);
+        else
+          hipLaunchKernelGGL(conv3x3s2_fast_kernel<F16>, dim3(p.nblocks), dim3(256), lds, st, p);
+      } else if (dtype == FRMAP_BF16)
         hipLaunchKernelGGL(conv3x3s2_split_kernel<BF16>, dim3(p.nblocks), dim3(256), lds, st, p);
       else
         hipLaunchKernelGGL(conv3x3s2_split_kernel<F16>, dim3(p.nblocks), dim3(256), lds, st, p);
