@@ -305,8 +305,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fast_kernel(const ConvParams p
     rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)w_base, (short)0, live ? wslab : 0, 0x00020000);
   };
   // piece j of a stage: j < NB halo pixels, then the 9 weight taps (already in LDS-image order)
+  int pso = 0;  // scalar byte offset of the halo loads (the chunk's 32 channels)
   auto prefetch1 = [&](int chunk, int j) {
-    if (j < NB) hv[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)soff[j], chunk * 64, 0);
+    if (j < NB) hv[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)soff[j], pso, 0);
     else wv[j - NB] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, tid * 16, (chunk * TAPS + (j - NB)) * 4096, 0);
   };
 
@@ -344,7 +345,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fast_kernel(const ConvParams p
       __syncthreads();
       // what the prefetch slots of this stage fetch
       const int pchunk = chunk + 1;
+      pso = pchunk * 64;
       set_rsrc(pchunk < p.nchunks);
+      if (pchunk == p.nchunks && p.res) {
+        // last chunk: the idle prefetch slots fetch this thread's 8 residual pieces (the epilogue's layout),
+        // so the residual tile lands under the MFMAs instead of being waited for in the epilogue
+        pso = 0;
+        const size_t rb = ((size_t)(p.M - m0) * p.Cout) * sizeof(elem);
+        rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)((const elem*)p.res + (size_t)m0 * p.Cout), (short)0,
+                                                  (int)(rb < 0x7FFFFFFFull ? rb : 0x7FFFFFFFull), 0x00020000);
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          const int idx = (u & 1) * 64 + lane, row = wave * 64 + (u >> 1) * 16 + (idx >> 3);
+          soff[u] = u < 8 && m0 + row < p.M ? (unsigned)((row * p.Cout + (nt << 6) + (idx & 7) * 8) * (int)sizeof(elem)) : 0xFFFFFF00u;
+        }
+      }
 
       vec8 wf[NI], pf[2][MI];
 #pragma unroll
@@ -378,7 +393,208 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fast_kernel(const ConvParams p
     // ---- epilogue: + shift (+ residual) (activation) -> NHWC, whole-line 16-byte stores via an LDS transpose
     __syncthreads();  // every wave is done reading the staged tiles; LDS is free for the transpose
     conv_epilogue<TT, MI, NI>(acc, smem + wave * (16 * (NI * 64 + 16)), m0 + wave * 64, p.M, p.Cout, nt << 6, p.shift,
-                              (const elem*)p.res, (elem*)p.out, p.relu, lane);
+                              (const elem*)p.res, (elem*)p.out, p.relu, lane, hv);
+  }
+}
+
+// ================================================================================================
+// 3x3 stride-1 layers with Cin = 64 and H, W multiples of 8 (ResNet layer1; BaselineNet conv3):
+// weights-resident kernel with WAVE-AUTONOMOUS tiles.
+//
+// With two chunks per tile conv3x3_fast_kernel re-stages the layer's whole 74 KB weight slab for
+// every 256 output pixels (47 % of all bytes a tile moves) and spends more time in barriers, LDS
+// writes and its epilogue than in MFMAs.  Here ONE 8-wave workgroup per CU loads the slab once, and
+// every wave then works alone: its tile is an 8x8 output patch x 64 channels, its halo is the
+// 10x10 input patch in a wave-private LDS image (pitch 16 pixels: a 16-pixel fragment = two 8-pixel
+// row segments lands on disjoint bank quads), and since only that wave ever touches the image the
+// in-order LDS pipeline is all the synchronisation there is - no barrier anywhere after start-up.
+// Eight independent instruction streams per CU cover each other's staging and epilogues.
+// Every global access rides between MFMAs: the next chunk's (or next tile's) 7 halo pieces, this
+// tile's 8 residual pieces, and the PREVIOUS tile's 8 packed output pieces (each one an 8-pixel x
+// 64-channel row segment = 1 KB contiguous), which the epilogue leaves in registers.
+// ================================================================================================
+template <typename TT>
+__global__ __launch_bounds__(512, 1) void conv3x3_c64_wave_kernel(const ConvParams p) {
+  constexpr int MI = 4, NI = 4, TAPS = 9, NH = 7, NO = 8, NG = TAPS * NI, NL = NO + NH;
+  constexpr int PITCH = NI * 64 + 16, HALO = 10 * 16 * 64;
+  using vec8 = typename TT::vec8;
+  using elem = typename TT::elem;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, g = lane >> 4;
+  constexpr int wbytes = 2 * TAPS * 4096;  // both chunks
+  char* wl = smem;
+  char* halo = smem + wbytes + wave * HALO;
+
+  const int ntiles = p.Cout >> 6;
+  const int Lb = xcd_remap_fwd(blockIdx.x, gridDim.x);
+  const int nt = Lb % ntiles, co0 = nt << 6;
+  const int tx = p.Wo >> 3, tpi = (p.Ho >> 3) * tx;  // 8x8 patches per row / per image
+  const int total = p.N * tpi;
+  const int wstride = (gridDim.x / ntiles) * 8;
+  int T = (Lb / ntiles) * 8 + wave;
+
+  {  // the resident weight slab of channel tile nt (both chunks, all taps), already in LDS-image order
+    const char* wsrc = (const char*)p.wpk + (size_t)nt * wbytes;
+    for (int o = tid * 16; o < wbytes; o += 512 * 16) *(u32x4_t*)(wl + o) = *(const u32x4_t*)(wsrc + o);
+  }
+  __syncthreads();
+  if (T >= total) return;
+
+  const int woff = (lr << 6) + ((g ^ (((lr >> 2) & 1) << 1)) << 4);
+  const elem* inp = (const elem*)p.in;
+  const int img_bytes = p.Hi * p.Wi * p.Cin * (int)sizeof(elem);
+  const int row_in = p.Wi * p.Cin * (int)sizeof(elem), row_out = p.Wo * p.Cout * (int)sizeof(elem);
+  // output / residual piece u (= output row u of the patch): lane -> pixel column lane >> 3, channels (lane & 7) * 8 ..+7
+  const int io_lane = ((lane >> 3) * p.Cout + co0 + (lane & 7) * 8) * (int)sizeof(elem);
+  float sh[8];
+  {
+    const f32x4_t s0 = *(const f32x4_t*)(p.shift + co0 + (lane & 7) * 8), s1 = *(const f32x4_t*)(p.shift + co0 + (lane & 7) * 8 + 4);
+    sh[0] = s0[0]; sh[1] = s0[1]; sh[2] = s0[2]; sh[3] = s0[3]; sh[4] = s1[0]; sh[5] = s1[1]; sh[6] = s1[2]; sh[7] = s1[3];
+  }
+  // fragment row i of pixel group mi = output pixel (mi*2 + (i >> 3), i & 7) of the patch = halo pixel (+kh, +kw)
+  int A[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) A[mi] = ((((mi * 2 + (lr >> 3)) << 4) + (lr & 7)) << 6) | (g << 4);
+
+  // halo piece u of this lane: q = u*64 + lane -> halo pixel q >> 2 = (pr, pc) of the 10x10 patch, channel group q & 3
+  unsigned soff[NH];
+  u32x4_t hv[NH], ov[NO];
+  __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)inp, (short)0, 0, 0x00020000);
+  int t_n = 0, t_by = 0, t_bx = 0;  // the tile the halo loads belong to
+  auto setup_load = [&](int t, bool live) {
+    t_n = t / tpi;
+    const int rem = t - t_n * tpi;
+    t_by = rem / tx; t_bx = rem - t_by * tx;
+    rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)(inp + (size_t)t_n * p.Hi * p.Wi * p.Cin), (short)0, live ? img_bytes : 0, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < NH; ++u) {
+      const int q = u * 64 + lane, px = q >> 2, cg = q & 3;
+      const int pr = (px * 205) >> 11, pc = px - pr * 10;  // px / 10 for px < 112
+      const int iy = t_by * 8 - 1 + pr, ix = t_bx * 8 - 1 + pc;
+      const bool ok = px < 100 && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      soff[u] = ok ? (unsigned)(iy * row_in + (ix * p.Cin + cg * 8) * (int)sizeof(elem)) : 0xFFFFFF00u;
+    }
+  };
+  auto io_rsrc = [&](const void* base, int n, int by, int bx, bool live) {  // descriptor at the patch's first pixel
+    const size_t el = (((size_t)n * p.Ho + by * 8) * p.Wo + bx * 8) * p.Cout;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const elem*)base + el), (short)0, live ? 8 * row_out : 0, 0x00020000);
+  };
+
+  setup_load(T, true);
+#pragma unroll
+  for (int u = 0; u < NH; ++u) hv[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)soff[u], 0, 0);
+  int p_n = -1, p_by = 0, p_bx = 0;  // the tile whose packed outputs sit in ov[]
+
+  for (; T < total; T += wstride) {
+    const int c_n = t_n, c_by = t_by, c_bx = t_bx;
+    f32x4_t acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int chunk = 0; chunk < 2; ++chunk) {
+      // stage: this wave's halo pieces -> its private image (LDS is in order: earlier fragment reads are served first)
+#pragma unroll
+      for (int u = 0; u < NH; ++u) {
+        const int q = u * 64 + lane, px = q >> 2;
+        const int pr = (px * 205) >> 11, pc = px - pr * 10;
+        if (px < 100) *(u32x4_t*)(halo + px_off<1>(pr * 16 + pc, q & 3)) = hv[u];
+      }
+      // ---- what rides between this phase's MFMAs
+      //  chunk 0: the previous tile's 8 output pieces (stores), then chunk 1's 7 halo pieces
+      //  chunk 1: this tile's 8 residual pieces (into ov[]), then the next tile's chunk-0 halo pieces
+      __amdgpu_buffer_rsrc_t rs_io;
+      int pso = 64;
+      if (chunk == 0) {
+        rs_io = io_rsrc(p.out, p_n < 0 ? 0 : p_n, p_by, p_bx, p_n >= 0);
+      } else {
+        rs_io = io_rsrc(p.res ? p.res : p.out, c_n, c_by, c_bx, p.res != nullptr);
+        pso = 0;
+        const bool more = T + wstride < total;
+        setup_load(more ? T + wstride : T, more);
+      }
+      auto memop = [&](int i) {
+        if (i < NO) {
+          if (chunk == 0) __builtin_amdgcn_raw_buffer_store_b128(ov[i], rs_io, io_lane, i * row_out, 0);
+          else ov[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_io, io_lane, i * row_out, 0);
+        } else {
+          hv[i - NO] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)soff[i - NO], pso, 0);
+        }
+      };
+
+      const char* wc = wl + chunk * (TAPS * 4096);
+      vec8 wf[NI], pf[2][MI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) asm volatile("" : "+v"(A[mi]));  // per-tap addresses: 3 VALU ops each, not 36 registers
+      auto paddr = [&](int mi, int t) {
+        const int at = A[mi] + (((t / 3) * 16 + (t % 3)) << 6);
+        return at ^ ((at >> 3) & 32);
+      };
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wf[ni] = *(const vec8*)(wc + ni * 1024 + woff);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) pf[0][mi] = *(const vec8*)(halo + paddr(mi, 0));
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        if (t + 1 < TAPS) {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) pf[(t + 1) & 1][mi] = *(const vec8*)(halo + paddr(mi, t + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = TT::mfma(wf[ni], pf[t & 1][mi], acc[mi][ni]);
+          if (t + 1 < TAPS) wf[ni] = *(const vec8*)(wc + (t + 1) * 4096 + ni * 1024 + woff);
+          const int k = t * NI + ni;
+          if ((k + 1) * NL / NG != k * NL / NG) memop(k * NL / NG);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    // ---- epilogue without stores: transpose two pixel groups at a time through the (now free) halo image,
+    //      + shift (+ residual from ov[]) (activation), round once, leave the 8 packed pieces in ov[]
+#pragma unroll
+    for (int mp = 0; mp < MI; mp += 2) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) *(f32x4_t*)(halo + h * (16 * PITCH) + lr * PITCH + ni * 64 + g * 16) = acc[mp + h][ni];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int prow = j * 8 + (lane >> 3), part = lane & 7, u = (mp + h) * 2 + j;
+          const f32x4_t a = *(const f32x4_t*)(halo + h * (16 * PITCH) + prow * PITCH + part * 32);
+          const f32x4_t b = *(const f32x4_t*)(halo + h * (16 * PITCH) + prow * PITCH + part * 32 + 16);
+          float v[8] = {a[0] + sh[0], a[1] + sh[1], a[2] + sh[2], a[3] + sh[3], b[0] + sh[4], b[1] + sh[5], b[2] + sh[6], b[3] + sh[7]};
+          if (p.res) {
+            float r[8];
+            unpack8<TT>(ov[u], r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+          }
+          if (p.relu == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+          } else if (p.relu == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));
+          }
+          ov[u] = pack8<TT>(v);
+        }
+    }
+    p_n = c_n; p_by = c_by; p_bx = c_bx;
+  }
+  // the last tile's outputs
+  if (p_n >= 0) {
+    const __amdgpu_buffer_rsrc_t rs_o = io_rsrc(p.out, p_n, p_by, p_bx, true);
+#pragma unroll
+    for (int i = 0; i < NO; ++i) __builtin_amdgcn_raw_buffer_store_b128(ov[i], rs_o, io_lane, i * row_out, 0);
   }
 }
 
@@ -911,6 +1127,40 @@ extern "C" int frmap_conv_igemm(const void* in, const void* w_packed, const floa
   // register-prefetch persistent kernel when the whole halo is <= 10 pieces per thread (and no ablation flag)
   const bool fastk = BM == 256 && stride == 1 && p.dbg == 0 && hb / 16 <= 10 * 256 && lds <= 80 * 1024 &&
                      (long long)(256 / (Ho * Wo) + 3) * Hi * Wi * Cin * 2 < (1ll << 31);
+  {
+    static int wres = -1;
+    if (wres < 0) { const char* e = getenv("FRMAP_CONV_WRES"); wres = e ? atoi(e) : 1; }
+    if (wres && stride == 1 && p.dbg == 0 && Cin == 64 && Hi % 8 == 0 && Wi % 8 == 0 &&
+        (long long)Hi * Wi * Cin * 2 < (1ll << 31) && (long long)8 * Wo * Cout * 2 < (1ll << 31)) {
+      const int total = B * (Hi / 8) * (Wi / 8);
+      int cus = 256;
+      {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+      }
+      int per = cus / ntiles;
+      if (per < 1) per = 1;
+      if (per > (total + 7) / 8) per = (total + 7) / 8;
+      const int grid = per * ntiles;
+      const int ldsw = 2 * wbytes + 8 * (10 * 16 * 64);
+      const void* kern = dtype == FRMAP_BF16 ? (const void*)conv3x3_c64_wave_kernel<BF16> : (const void*)conv3x3_c64_wave_kernel<F16>;
+      static bool attr[2] = {false, false};
+      if (!attr[dtype]) {
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+          frmap_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+          return -2;
+        }
+        attr[dtype] = true;
+      }
+      if (dtype == FRMAP_BF16)
+        hipLaunchKernelGGL(conv3x3_c64_wave_kernel<BF16>, dim3(grid), dim3(512), ldsw, st, p);
+      else
+        hipLaunchKernelGGL(conv3x3_c64_wave_kernel<F16>, dim3(grid), dim3(512), ldsw, st, p);
+      FRMAP_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   if (fastk) {
     const int grid = p.nblocks;
     const void* kern = dtype == FRMAP_BF16 ? (const void*)conv3x3_fast_kernel<BF16> : (const void*)conv3x3_fast_kernel<F16>;

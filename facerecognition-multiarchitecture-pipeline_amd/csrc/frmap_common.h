@@ -75,11 +75,15 @@ __device__ __forceinline__ u32x4_t pack8(const float* f) {
 // Caller guarantees: all waves are past their last read of the LDS tiles (a barrier), `scratch`
 // is this wave's private 16*(NI*64+16)-byte region, 16-byte aligned.
 // ------------------------------------------------------------------------------------------------
+// `rv_pre` (optional): the residual pieces already in registers, rv_pre[mi * PER_LANE + j] = the 16 bytes
+// at (pixel m_wave0 + mi*16 + (j*64 + lane) / PARTS, channels co0 + ((j*64 + lane) % PARTS) * 8 ..+7);
+// `res` is then only a flag (non-null = add them).
 template <typename TT, int MI, int NI>
 __device__ __forceinline__ void conv_epilogue(const f32x4_t (&acc)[MI][NI], char* scratch, int m_wave0, int M,
                                               int Cout, int co0, const float* __restrict__ shift,
                                               const typename TT::elem* __restrict__ res,
-                                              typename TT::elem* __restrict__ out, int relu, int lane) {
+                                              typename TT::elem* __restrict__ out, int relu, int lane,
+                                              const u32x4_t* rv_pre = nullptr) {
   constexpr int PITCH = NI * 64 + 16;      // bytes per pixel row in scratch
   constexpr int PARTS = NI * 2;            // 8-channel runs per pixel
   constexpr int PER_LANE = PARTS / 4;      // (16 px * PARTS) / 64 lanes
@@ -106,7 +110,8 @@ __device__ __forceinline__ void conv_epilogue(const f32x4_t (&acc)[MI][NI], char
       for (int j = 0; j < PER_LANE; ++j) {
         const int m = m_wave0 + mi * 16 + prow[j];
         rv[mi][j] = (u32x4_t){0u, 0u, 0u, 0u};
-        if (m < M) rv[mi][j] = *(const u32x4_t*)(res + (size_t)m * Cout + co0 + part[j] * 8);
+        if (rv_pre) rv[mi][j] = rv_pre[mi * PER_LANE + j];
+        else if (m < M) rv[mi][j] = *(const u32x4_t*)(res + (size_t)m * Cout + co0 + part[j] * 8);
       }
   }
 #pragma unroll

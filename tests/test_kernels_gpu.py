@@ -27,7 +27,11 @@ def _tol(dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,res,relu", [
-    (2, 56, 56, 64, 64, 3, 1, True, True),       # resnet layer1
+    (2, 56, 56, 64, 64, 3, 1, True, True),       # resnet layer1 (wave-autonomous weights-resident kernel)
+    (3, 16, 24, 64, 128, 3, 1, True, True),      # same kernel: 2 channel tiles, 18 patches (fewer than waves)
+    (1, 8, 8, 64, 64, 3, 1, False, False),       # same kernel: a single 8x8 patch
+    (5, 24, 8, 64, 64, 3, 1, False, True),       # same kernel: one patch column
+    (2, 20, 56, 64, 64, 3, 1, True, True),       # H not a multiple of 8 -> register-prefetch kernel
     (3, 56, 56, 64, 128, 3, 2, False, True),     # layer2.0.conv1 (stride 2)
     (3, 56, 56, 64, 128, 1, 2, False, False),    # layer2.0.downsample
     (5, 28, 28, 128, 128, 3, 1, True, True),
