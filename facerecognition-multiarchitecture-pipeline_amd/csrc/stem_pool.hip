@@ -39,6 +39,14 @@ struct StemPoolParams {
 //                advance by 14 (7 pooled columns each), first conv row/column of a tile is 2*p0 - 1.
 // POOL3 = false: MaxPool2d(2, 2)    (SiameseNet conv.0-3, face_models.py:115-118): 6 conv rows -> 3 pooled
 //                rows, strips of 16 conv columns -> 8 pooled columns, no overlap.
+// value of lane i+N of the same 16-lane row (N = 1, 2); the row's last lanes keep their own value.
+// A DPP row shift is one VALU op; __shfl_down compiles to ds_bpermute (an LDS round trip per call).
+template <int N>
+__device__ __forceinline__ float row_down(float v) {
+  const int i = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x100 + N, 0xF, 0xF, false));
+}
+
 template <typename TT, bool POOL3>
 __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams p) {
   constexpr int MI = POOL3 ? 7 : 6, NI = 4, KSTEPS = 7, KPAD = 224, WPITCH = (KPAD + 8) * 2;
@@ -138,14 +146,17 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
       }
       // mask conv positions outside the image (they act as -inf under the max), pool, store
       const int cc = CSTEP * strip + lr - (POOL3 ? 1 : 0);  // this lane's conv column
-      const bool colv = (unsigned)cc < (unsigned)p.Wc;
+      const int cc_lo = CSTEP * strip - (POOL3 ? 1 : 0);     // (wave-uniform) first conv column of the strip
+      if (cc_lo < 0 || cc_lo + 15 >= p.Wc || cr0 < 0 || cr0 + MI > p.Hc) {  // only border strips / row groups pay for the masking
+        const bool colv = (unsigned)cc < (unsigned)p.Wc;
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        const bool v = colv && (unsigned)(cr0 + mi) < (unsigned)p.Hc;
+        for (int mi = 0; mi < MI; ++mi) {
+          const bool v = colv && (unsigned)(cr0 + mi) < (unsigned)p.Hc;
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
+          for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[mi][ni][e] = v ? acc[mi][ni][e] : -INFINITY;
+            for (int e = 0; e < 4; ++e) acc[mi][ni][e] = v ? acc[mi][ni][e] : -INFINITY;
+        }
       }
 #pragma unroll
       for (int pr = 0; pr < 3; ++pr) {
@@ -157,10 +168,10 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
             float m;
             if (POOL3) {
               m = fmaxf(fmaxf(acc[2 * pr][ni][e], acc[2 * pr + 1][ni][e]), acc[2 * pr + 2][ni][e]);  // rows
-              m = fmaxf(m, fmaxf(__shfl_down(m, 1, 16), __shfl_down(m, 2, 16)));                       // columns
+              m = fmaxf(m, fmaxf(row_down<1>(m), row_down<2>(m)));                                     // columns
             } else {
               m = fmaxf(acc[2 * pr][ni][e], acc[2 * pr + 1][ni][e]);
-              m = fmaxf(m, __shfl_down(m, 1, 16));
+              m = fmaxf(m, row_down<1>(m));
             }
             v[e] = m;
           }
