@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="faces per GPU per step")
     ap.add_argument("--gallery", type=int, default=36)
-    ap.add_argument("--model", default="cnn", choices=["cnn", "arcface", "baseline", "siamese", "hybrid"])
+    ap.add_argument("--model", default="cnn", choices=["cnn", "arcface", "baseline", "siamese", "hybrid", "attention"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--streams", type=int, default=2, help="split the per-GPU batch over this many concurrent HIP streams")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step from a captured HIP graph (0: eager launches)")
@@ -102,7 +102,7 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(2002 + rank)
     x = torch.randn((B, 3, 224, 224), device=dev, dtype=torch.float32, generator=gen)  # resident in HBM
-    need_norm = args.model in ("cnn", "baseline", "hybrid")
+    need_norm = args.model in ("cnn", "baseline", "hybrid", "attention")
     total = B * world
 
     graphed, graph_note = None, ""
@@ -214,7 +214,8 @@ def main():
         xc = x[:nb].cpu()
         gal = gallery.matrix.cpu()
         emb_fn = {"cnn": fo.cnn_embedding, "arcface": fo.arcface_embedding, "baseline": fo.baseline_embedding,
-                  "siamese": fo.siamese_forward_one, "hybrid": fo.hybrid_embedding}[args.model]
+                  "siamese": fo.siamese_forward_one, "hybrid": fo.hybrid_embedding,
+                  "attention": fo.attention_embedding}[args.model]
         best = float("inf")
         with torch.no_grad():
             for rep in range(4):

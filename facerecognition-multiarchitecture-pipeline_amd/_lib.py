@@ -13,7 +13,7 @@ import threading
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libfrmap_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lock = threading.Lock()
 _lib = None
@@ -44,6 +44,7 @@ PROTOTYPES = {
     "frmap_add_pos_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
     "frmap_mha_tokens": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "frmap_mean_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
+    "frmap_cnn_attention": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "frmap_normalize_u8_hwc": (_i, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _vp]),
     "frmap_softmax_argmax": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "frmap_pairwise_distance": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp]),

@@ -13,5 +13,5 @@ void frmap_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int frmap_abi_version(void) { return 3; }
+extern "C" int frmap_abi_version(void) { return 4; }
 extern "C" const char* frmap_last_error(void) { return g_err; }

@@ -282,3 +282,197 @@ extern "C" int frmap_mean_layernorm(const void* t, const float* gamma, const flo
   FRMAP_LAUNCH_CHECK();
   return 0;
 }
+
+// ================================================================================================
+// AttentionNet's attention block on the trunk's H x W x C map (`/root/reference/src/face_models.py:194-262`),
+// one workgroup per image, everything after the fused 1x1 q/k/v projection in ONE kernel:
+//   energy = q . k^T over the L = H*W positions -> softmax rows -> out[i][c] = sum_j attn[i][j] v[j][c]
+//   y = gamma * out + x                                   (AttentionModule, `:233-252`)
+//   gate = sigmoid(conv KSxKS([mean_c y, max_c y]) + b)    (SpatialAttention, `:194-211`)
+//   map = y * gate ; pool = mean over positions            (+ AttentionNet's AdaptiveAvgPool2d(1), `:279`)
+// qkv is the packed projection [B][L][2*Cq + C] (q | k | v) a single 1x1 conv emits; thread t owns
+// channels t, t + 256, ... (CPT of them) of every position, so y never leaves registers, the channel
+// mean / max are a wave reduction + 4-way LDS combine, and the final pooling is thread-local.
+// All arithmetic is fp32 on the storage-dtype inputs.
+// ================================================================================================
+struct CnnAttnParams {
+  const void* qkv;
+  const void* x;
+  const float* gamma;
+  const float* sw;   // [2][KS][KS]
+  const float* sb;   // [1]
+  void* out_map;     // [B][L][C] storage dtype, or null
+  float* out_pool;   // [B][C] fp32, or null
+  int B, H, W, L, Cq, C, KS;
+};
+
+template <typename TT, int CPT, int LMAX>
+__global__ __launch_bounds__(256) void cnn_attention_kernel(const CnnAttnParams p) {
+  using elem = typename TT::elem;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int L = p.L, Cq = p.Cq, C = p.C, RS = 2 * Cq + C;  // row stride of qkv in elements
+  const int QP = Cq + 1;                                     // padded pitch of the fp32 q / k images
+  float* qs = (float*)smem;
+  float* ks = qs + LMAX * QP;
+  float* at = ks + LMAX * QP;            // attention, pitch LMAX + 1
+  float* part = at + LMAX * (LMAX + 1);  // [4 waves][2][LMAX] channel sum / max partials
+  float* gate = part + 4 * 2 * LMAX;     // [LMAX] mean, [LMAX] max, [LMAX] gate
+  elem* vs = (elem*)(gate + 3 * LMAX);   // [L][C] storage dtype
+  const size_t b = blockIdx.x;
+  const elem* qkv = (const elem*)p.qkv + b * (size_t)L * RS;
+  const elem* xb = (const elem*)p.x + b * (size_t)L * C;
+
+  for (int i = tid; i < L * Cq; i += 256) {
+    const int r = i / Cq, c = i - r * Cq;
+    qs[r * QP + c] = TT::to_f32(qkv[(size_t)r * RS + c]);
+    ks[r * QP + c] = TT::to_f32(qkv[(size_t)r * RS + Cq + c]);
+  }
+  for (int i = tid; i < L * (C / 8); i += 256) {
+    const int r = i / (C / 8), c8 = i - r * (C / 8);
+    *(u32x4_t*)(vs + (size_t)r * C + c8 * 8) = *(const u32x4_t*)(qkv + (size_t)r * RS + 2 * Cq + c8 * 8);
+  }
+  __syncthreads();
+  for (int e = tid; e < L * L; e += 256) {
+    const int i = e / L, j = e - i * L;
+    float s = 0.f;
+    for (int c = 0; c < Cq; ++c) s = fmaf(qs[i * QP + c], ks[j * QP + c], s);
+    at[i * (LMAX + 1) + j] = s;
+  }
+  __syncthreads();
+  if (tid < L) {  // softmax over j, as F.softmax: exp(x - max) / sum
+    float* row = at + tid * (LMAX + 1);
+    float m = row[0];
+    for (int j = 1; j < L; ++j) m = fmaxf(m, row[j]);
+    float sum = 0.f;
+    for (int j = 0; j < L; ++j) { const float e = expf(row[j] - m); row[j] = e; sum += e; }
+    const float inv = 1.0f / sum;
+    for (int j = 0; j < L; ++j) row[j] *= inv;
+  }
+  __syncthreads();
+
+  float y[LMAX][CPT];
+#pragma unroll
+  for (int i = 0; i < LMAX; ++i)
+#pragma unroll
+    for (int cc = 0; cc < CPT; ++cc) y[i][cc] = 0.f;
+  for (int j = 0; j < L; ++j) {
+    float vj[CPT];
+#pragma unroll
+    for (int cc = 0; cc < CPT; ++cc) vj[cc] = TT::to_f32(vs[(size_t)j * C + tid + 256 * cc]);
+#pragma unroll
+    for (int i = 0; i < LMAX; ++i) {
+      const float a = i < L ? at[i * (LMAX + 1) + j] : 0.f;  // same address in every lane: an LDS broadcast
+#pragma unroll
+      for (int cc = 0; cc < CPT; ++cc) y[i][cc] = fmaf(a, vj[cc], y[i][cc]);
+    }
+  }
+  const float gamma = p.gamma[0];
+#pragma unroll
+  for (int i = 0; i < LMAX; ++i) {
+    float s = 0.f, m = -INFINITY;
+    if (i < L) {
+#pragma unroll
+      for (int cc = 0; cc < CPT; ++cc) {
+        y[i][cc] = fmaf(gamma, y[i][cc], TT::to_f32(xb[(size_t)i * C + tid + 256 * cc]));
+        s += y[i][cc];
+        m = fmaxf(m, y[i][cc]);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s += __shfl_xor(s, o);
+      m = fmaxf(m, __shfl_xor(m, o));
+    }
+    if (lane == 0 && i < L) {
+      part[(wave * 2 + 0) * LMAX + i] = s;
+      part[(wave * 2 + 1) * LMAX + i] = m;
+    }
+  }
+  __syncthreads();
+  if (tid < L) {
+    float s = 0.f, m = -INFINITY;
+    for (int w = 0; w < 4; ++w) {
+      s += part[(w * 2 + 0) * LMAX + tid];
+      m = fmaxf(m, part[(w * 2 + 1) * LMAX + tid]);
+    }
+    gate[tid] = s / (float)C;
+    gate[LMAX + tid] = m;
+  }
+  __syncthreads();
+  if (tid < L) {
+    const int oy = tid / p.W, ox = tid - oy * p.W, KS = p.KS, pad = KS / 2;
+    float g = p.sb[0];
+    for (int ch = 0; ch < 2; ++ch)
+      for (int dy = 0; dy < KS; ++dy) {
+        const int iy = oy + dy - pad;
+        if ((unsigned)iy >= (unsigned)p.H) continue;
+        for (int dx = 0; dx < KS; ++dx) {
+          const int ix = ox + dx - pad;
+          if ((unsigned)ix < (unsigned)p.W) g = fmaf(p.sw[(ch * KS + dy) * KS + dx], gate[ch * LMAX + iy * p.W + ix], g);
+        }
+      }
+    gate[2 * LMAX + tid] = 1.0f / (1.0f + expf(-g));
+  }
+  __syncthreads();
+  float pool[CPT];
+#pragma unroll
+  for (int cc = 0; cc < CPT; ++cc) pool[cc] = 0.f;
+  elem* om = p.out_map ? (elem*)p.out_map + b * (size_t)L * C : nullptr;
+#pragma unroll
+  for (int i = 0; i < LMAX; ++i)
+    if (i < L) {
+      const float gt = gate[2 * LMAX + i];
+#pragma unroll
+      for (int cc = 0; cc < CPT; ++cc) {
+        const float o = y[i][cc] * gt;
+        pool[cc] += o;
+        if (om) om[(size_t)i * C + tid + 256 * cc] = TT::from_f32(o);
+      }
+    }
+  if (p.out_pool)
+#pragma unroll
+    for (int cc = 0; cc < CPT; ++cc) p.out_pool[b * C + tid + 256 * cc] = pool[cc] / (float)L;
+}
+
+template <typename TT, int CPT, int LMAX>
+static int cnn_attention_launch(const CnnAttnParams& p, hipStream_t st) {
+  const size_t lds = (size_t)(2 * LMAX * (p.Cq + 1) + LMAX * (LMAX + 1) + 8 * LMAX + 3 * LMAX) * sizeof(float) +
+                     (size_t)p.L * p.C * sizeof(typename TT::elem);
+  FRMAP_REQUIRE(lds <= 160 * 1024, "cnn_attention: %zu bytes of LDS needed (> 160 KB)", lds);
+  auto kern = cnn_attention_kernel<TT, CPT, LMAX>;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      frmap_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return -2;
+    }
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.B), dim3(256), lds, st, p);
+  FRMAP_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int frmap_cnn_attention(const void* qkv, const void* x, const float* gamma, const float* spatial_w,
+                                   const float* spatial_b, void* out_map, float* out_pool, int B, int H, int W, int Cq,
+                                   int C, int KS, int dtype, void* stream) {
+  FRMAP_REQUIRE(qkv && x && gamma && spatial_w && spatial_b, "cnn_attention: null pointer");
+  FRMAP_REQUIRE(out_map || out_pool, "cnn_attention: no output requested");
+  FRMAP_REQUIRE(dtype == FRMAP_BF16 || dtype == FRMAP_F16, "cnn_attention: bad dtype");
+  FRMAP_REQUIRE(B > 0 && H > 0 && W > 0 && H * W <= 64, "cnn_attention: need 1 <= H*W <= 64 (got %dx%d)", H, W);
+  FRMAP_REQUIRE(Cq > 0 && Cq <= 128 && Cq % 8 == 0, "cnn_attention: Cq=%d must be a multiple of 8, <= 128", Cq);
+  FRMAP_REQUIRE(C == 256 || C == 512, "cnn_attention: C=%d must be 256 or 512", C);
+  FRMAP_REQUIRE(KS > 0 && KS % 2 == 1 && KS <= 15, "cnn_attention: odd spatial kernel size <= 15 expected (got %d)", KS);
+  CnnAttnParams p;
+  p.qkv = qkv; p.x = x; p.gamma = gamma; p.sw = spatial_w; p.sb = spatial_b; p.out_map = out_map; p.out_pool = out_pool;
+  p.B = B; p.H = H; p.W = W; p.L = H * W; p.Cq = Cq; p.C = C; p.KS = KS;
+  hipStream_t st = (hipStream_t)stream;
+  const bool big = p.L > 49;
+#define FRMAP_CA(TT)                                                                                  \
+  (C == 512 ? (big ? cnn_attention_launch<TT, 2, 64>(p, st) : cnn_attention_launch<TT, 2, 49>(p, st)) \
+            : (big ? cnn_attention_launch<TT, 1, 64>(p, st) : cnn_attention_launch<TT, 1, 49>(p, st)))
+  return dtype == FRMAP_BF16 ? FRMAP_CA(BF16) : FRMAP_CA(F16);
+#undef FRMAP_CA
+}

@@ -564,13 +564,146 @@ class HybridNet(_HipModule):
 
 
 # --------------------------------------------------------------------------------------------
+# §8(f) AttentionNet (face_models.py:194-295) and EnsembleModel (face_models.py:843-959)
+# --------------------------------------------------------------------------------------------
+class SpatialAttention(nn.Module):
+    """Parameter container, `face_models.py:194-211` (the gate itself runs inside ``frmap_cnn_attention``)."""
+
+    def __init__(self, kernel_size=7):
+        super().__init__()
+        self.conv = nn.Conv2d(2, 1, kernel_size=kernel_size, padding=kernel_size // 2)
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, x):
+        raise RuntimeError("SpatialAttention is a parameter container here; run AttentionNet on the GPU")
+
+
+class AttentionModule(nn.Module):
+    """Parameter container, `face_models.py:213-262`."""
+
+    def __init__(self, in_channels, reduction_ratio=8):
+        super().__init__()
+        self.query = nn.Conv2d(in_channels, in_channels // reduction_ratio, kernel_size=1)
+        self.key = nn.Conv2d(in_channels, in_channels // reduction_ratio, kernel_size=1)
+        self.value = nn.Conv2d(in_channels, in_channels, kernel_size=1)
+        self.gamma = nn.Parameter(torch.zeros(1))
+        self.gamma_value = 0.0
+        self.num_heads = 2
+        self.head_dim = in_channels // (reduction_ratio * self.num_heads)
+        self.spatial_attention = SpatialAttention()
+
+    def forward(self, x):
+        raise RuntimeError("AttentionModule is a parameter container here; run AttentionNet on the GPU")
+
+
+class AttentionNet(_HipModule):
+    """`face_models.py:264-295`: ResNet-18 trunk (no pool) → AttentionModule → global average pool → fc.
+    q/k/v are ONE 1x1 conv (the three weight matrices stacked along Cout, biases as its shift); everything after it
+    up to and including the pooling is ``frmap_cnn_attention``."""
+
+    def __init__(self, num_classes=18, dropout_rate=0.25):
+        super().__init__()
+        self.backbone = ResNet18()
+        self.features = nn.Sequential(*list(self.backbone.children())[:-2])
+        self.attention = AttentionModule(512)
+        self.gap = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Linear(512, num_classes)
+
+    def _build_plan(self, dtype):
+        a = self.attention
+        w = torch.cat([a.query.weight, a.key.weight, a.value.weight], dim=0).detach().float()
+        bias = torch.cat([a.query.bias, a.key.bias, a.value.bias], dim=0).detach().float()
+        return {"trunk": _TrunkPlan(self.backbone, dtype), "qkv": ops.pack_conv_weight(w.contiguous(), dtype),
+                "qkv_bias": bias.contiguous(), "cq": a.query.weight.shape[0], "cqkv": w.shape[0],
+                "gamma": a.gamma.detach().float().contiguous(),
+                "sw": a.spatial_attention.conv.weight.detach().float().contiguous(),
+                "sb": a.spatial_attention.conv.bias.detach().float().contiguous()}
+
+    def _attend(self, x, want_map):
+        x = self._check_input(x)
+        p = self._get_plan()
+        f = p["trunk"].features(x)                                                   # NHWC B×H×W×512
+        qkv = ops.conv_igemm(f, p["qkv"], p["qkv_bias"], p["cqkv"], 1, 1, 0, 0)        # q | k | v  (+bias)
+        return ops.cnn_attention(qkv, f, p["gamma"], p["sw"], p["sb"], p["cq"], want_map=want_map, want_pool=True)
+
+    def get_embedding(self, x):
+        """`face_models.py:284-288`."""
+        return self._attend(x, False)[1]
+
+    def forward(self, x):
+        """`face_models.py:276-282`."""
+        return ops.linear_f32(self.get_embedding(x), self.fc.weight.detach(), None, self.fc.bias.detach())
+
+    def attention_map(self, x):
+        """The attended map the module hands to the pooling, NCHW-logical (stored NHWC): B×H×W×512."""
+        return self._attend(x, True)[0]
+
+    def get_attention_params(self):
+        self.attention.gamma_value = float(self.attention.gamma.detach().cpu().item())
+        return {"gamma": self.attention.gamma_value}
+
+
+class EnsembleModel(nn.Module):
+    """`face_models.py:843-941`: runs every member on the GPU and merges their logits on the device.
+    ArcFace members contribute cosine logits against their class centres (`:889-893`), Siamese members are
+    skipped (`:894-897`); 'average' / 'weighted' / 'max' as in the reference, anything else raises ValueError
+    at call time (`:919-920` — the constructor accepts 'attention' but ``forward`` has no branch for it)."""
+
+    def __init__(self, models, ensemble_method: str = 'weighted'):
+        super().__init__()
+        self.models = nn.ModuleList(models)
+        self.ensemble_method = ensemble_method
+        self.weights = nn.Parameter(torch.ones(len(models)) / len(models),
+                                    requires_grad=(ensemble_method in ['weighted', 'attention']))
+        if ensemble_method == 'attention':
+            self.attention_net = nn.Sequential(nn.Linear(len(models), 64), nn.ReLU(inplace=True),
+                                               nn.Linear(64, len(models)), nn.Softmax(dim=0))
+
+    def forward(self, x):
+        outputs = []
+        for model in self.models:
+            if hasattr(model, 'training') and model.training:
+                model.eval()
+            if isinstance(model, ArcFaceNet):
+                emb = model(x)                                                            # unit-norm embedding
+                outputs.append(ops.cosine_logits(emb, model.arcface.weight.detach().float(), want_argmax=False)[0])
+            elif isinstance(model, SiameseNet):
+                continue
+            else:
+                outputs.append(model(x))
+        if len(outputs) == 1:
+            return outputs[0]
+        if self.ensemble_method == 'average':
+            return torch.mean(torch.stack(outputs), dim=0)
+        elif self.ensemble_method == 'weighted':
+            w = torch.softmax(self.weights.detach().float(), dim=0)
+            return torch.sum(torch.stack([w[i] * outputs[i] for i in range(len(outputs))]), dim=0)
+        elif self.ensemble_method == 'max':
+            probs = [torch.softmax(o, dim=1) for o in outputs]
+            return torch.log(torch.max(torch.stack(probs), dim=0)[0])
+        raise ValueError(f"Unknown ensemble method: {self.ensemble_method}")
+
+    def get_embedding(self, x):
+        """`face_models.py:922-941`: the members' embeddings concatenated along the feature axis."""
+        embs = [m.get_embedding(x) for m in self.models if hasattr(m, 'get_embedding')]
+        embs = [e.unsqueeze(0) if e.dim() == 1 else e for e in embs]
+        if len(embs) > 1:
+            return torch.cat(embs, dim=1)
+        return embs[0] if embs else None
+
+
+def create_ensemble(model_types, num_classes: int, ensemble_method: str = 'average') -> EnsembleModel:
+    """`face_models.py:943-959`."""
+    return EnsembleModel([get_model(t, num_classes=num_classes) for t in model_types], ensemble_method=ensemble_method)
+
+
+# --------------------------------------------------------------------------------------------
 # a1  factory
 # --------------------------------------------------------------------------------------------
 def get_model(model_type: str, num_classes: int = 18, input_size: Tuple[int, int] = (224, 224)) -> nn.Module:
     """`face_models.py:785-813`: same type strings; unknown → ``ValueError``.  Returns a train-mode
     module on the CPU with fp32 parameters, as the reference does; ``.to('cuda').eval()`` before
-    inference.  'attention' / 'ensemble' (and list inputs) are valid names in the reference but are
-    outside this build's hot-path scope and raise ``NotImplementedError``."""
+    inference."""
     if model_type == 'baseline':
         return BaselineNet(num_classes=num_classes, input_size=input_size)
     elif model_type == 'cnn':
@@ -581,7 +714,11 @@ def get_model(model_type: str, num_classes: int = 18, input_size: Tuple[int, int
         return ArcFaceNet(num_classes=num_classes, dropout_rate=0.2)
     elif model_type == 'hybrid':
         return HybridNet(num_classes=num_classes)
-    elif model_type in ('attention', 'ensemble') or isinstance(model_type, list):
-        raise NotImplementedError(f"model type {model_type!r} is outside the MI355X hot-path scope (SURVEY.md §2.2)")
+    elif model_type == 'attention':
+        return AttentionNet(num_classes=num_classes, dropout_rate=0.25)
+    elif model_type == 'ensemble':
+        return create_ensemble(['cnn', 'attention', 'arcface'], num_classes=num_classes)
+    elif isinstance(model_type, list):
+        return create_ensemble(model_type, num_classes=num_classes)
     else:
         raise ValueError(f"Invalid model type: {model_type}")

@@ -261,6 +261,28 @@ def mean_layernorm(t: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps
     return out
 
 
+def cnn_attention(qkv: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, spatial_w: torch.Tensor, spatial_b: torch.Tensor,
+                  Cq: int, want_map: bool = False, want_pool: bool = True):
+    """AttentionNet's attention block (`face_models.py:194-262`) on an NHWC trunk map ``x`` [B,H,W,C] given the packed
+    q|k|v projection ``qkv`` [B,H,W,2*Cq+C].  Returns (map [B,H,W,C] | None, pooled fp32 [B,C] | None)."""
+    x = _dev(x, "cnn_attention.x")
+    qkv = _dev(qkv, "cnn_attention.qkv", x.dtype)
+    B, H, W, C = x.shape
+    if tuple(qkv.shape) != (B, H, W, 2 * Cq + C):
+        raise ValueError(f"cnn_attention: qkv shape {tuple(qkv.shape)} != {(B, H, W, 2 * Cq + C)}")
+    sw = _dev(spatial_w, "spatial_w", torch.float32)
+    KS = sw.shape[-1]
+    if sw.numel() != 2 * KS * KS:
+        raise ValueError("cnn_attention: spatial_w must be [1][2][KS][KS]")
+    om = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device) if want_map else None
+    op = torch.empty((B, C), dtype=torch.float32, device=x.device) if want_pool else None
+    _lib.check(_lib.load().frmap_cnn_attention(qkv.data_ptr(), x.data_ptr(), _dev(gamma, "gamma", torch.float32).data_ptr(),
+                                               sw.data_ptr(), _dev(spatial_b, "spatial_b", torch.float32).data_ptr(),
+                                               om.data_ptr() if om is not None else 0, op.data_ptr() if op is not None else 0,
+                                               B, H, W, Cq, C, KS, dt_code(x.dtype), _stream()), "cnn_attention")
+    return om, op
+
+
 def normalize_u8(img: torch.Tensor, mean, std, want_nchw: bool = True, nhwc4_dtype: Optional[torch.dtype] = None):
     """uint8 [B, H, W, 3] RGB on the GPU → ToTensor + Normalize.  Returns (fp32 NCHW | None, NHWC4 | None)."""
     import ctypes as C

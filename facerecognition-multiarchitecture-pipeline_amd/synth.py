@@ -63,7 +63,7 @@ def synth_state_dict(shapes: Mapping[str, Tuple[Tuple[int, ...], torch.dtype]], 
     Rules (by key suffix): conv / linear ``weight`` -> N(0, 2/fan_in); norm-layer ``weight`` ->
     U(0.5, 1.5); ``bias`` -> N(0, 0.05²); ``running_mean`` -> N(0, 0.1²); ``running_var`` ->
     U(0.5, 1.5); ``num_batches_tracked`` and ``arcface.u`` -> 0; ``pos_encoding`` -> N(0, 0.02²)
-    (`face_models.py:668`).
+    (`face_models.py:668`); ``gamma`` -> U(0.3, 0.8).
     """
     keys = list(shapes.keys())
     tp = trunk_prefix_of(keys)
@@ -83,6 +83,8 @@ def synth_state_dict(shapes: Mapping[str, Tuple[Tuple[int, ...], torch.dtype]], 
             t = torch.from_numpy((0.1 * g.standard_normal(shape)).astype(np.float32))
         elif leaf == "running_var":
             t = torch.from_numpy(g.uniform(0.5, 1.5, shape).astype(np.float32))
+        elif leaf == "gamma":  # AttentionModule.gamma (`face_models.py:220`, zeros at init: the branch would be inert)
+            t = torch.from_numpy(g.uniform(0.3, 0.8, shape).astype(np.float32))
         elif leaf == "pos_encoding":
             t = torch.from_numpy((0.02 * g.standard_normal(shape)).astype(np.float32))
         elif leaf in ("bias", "in_proj_bias"):

@@ -165,6 +165,21 @@ int frmap_mean_layernorm(const void* t, const float* gamma, const float* beta, f
                          int B, int L, int D, float eps, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * AttentionNet's attention block on the trunk map   (/root/reference/src/face_models.py:194-262, GAP :279)
+ *   qkv       : [B][H*W][2*Cq + C] (dtype): the 1x1 query | key | value projections (+bias) of x, packed
+ *               (one frmap_conv_igemm with the three weight matrices stacked along Cout)
+ *   x         : [B][H*W][C] (dtype), the trunk map (NHWC)
+ *   gamma     : device float[1]  (AttentionModule.gamma, :220)
+ *   spatial_w : device fp32 [2][KS][KS], spatial_b: device float[1]  (SpatialAttention.conv, :199; pad KS/2)
+ *   out_map   : [B][H*W][C] (dtype) = (gamma * softmax(q k^T) v + x) * sigmoid(conv([mean_c, max_c]))  or NULL
+ *   out_pool  : fp32 [B][C] = mean over the H*W positions of that map (AdaptiveAvgPool2d(1))            or NULL
+ *   H*W <= 64, Cq <= 128 (multiple of 8), C in {256, 512}, KS odd.
+ * ------------------------------------------------------------------------------------------- */
+int frmap_cnn_attention(const void* qkv, const void* x, const float* gamma, const float* spatial_w,
+                        const float* spatial_b, void* out_map, float* out_pool, int B, int H, int W, int Cq,
+                        int C, int KS, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Gallery matching (fp32, exact-f32 MFMA).
  *   frmap_match_top1 : for each probe row e (B×D) the FIRST index minimising
  *                      || e - g_i + 1e-6 ||_2 over gallery rows g (G×D) and that distance —

@@ -245,6 +245,56 @@ def hybrid_forward(sd: SD, x: torch.Tensor) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------------------------
+# §8(f) AttentionNet  (face_models.py:194-295)   EnsembleModel combination (face_models.py:880-926)
+# --------------------------------------------------------------------------------------------
+def attention_module(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """`face_models.py:213-262` (AttentionModule) + `:194-211` (SpatialAttention): 1×1 q/k/v projections,
+    softmax(qᵀk) over the H·W positions, ``gamma * (v · attnᵀ) + x``, then the 7×7 spatial gate on the
+    channel-mean / channel-max maps."""
+    B, C, H, W = x.shape
+    q = F.conv2d(x, sd[p + "query.weight"], sd[p + "query.bias"]).view(B, -1, H * W).permute(0, 2, 1)
+    k = F.conv2d(x, sd[p + "key.weight"], sd[p + "key.bias"]).view(B, -1, H * W)
+    v = F.conv2d(x, sd[p + "value.weight"], sd[p + "value.bias"]).view(B, -1, H * W)
+    attention = F.softmax(torch.bmm(q, k), dim=-1)
+    out = torch.bmm(v, attention.permute(0, 2, 1)).view(B, C, H, W)
+    y = sd[p + "gamma"] * out + x
+    pooled = torch.cat([y.mean(dim=1, keepdim=True), y.max(dim=1, keepdim=True)[0]], dim=1)
+    gate = torch.sigmoid(F.conv2d(pooled, sd[p + "spatial_attention.conv.weight"], sd[p + "spatial_attention.conv.bias"],
+                                  padding=sd[p + "spatial_attention.conv.weight"].shape[-1] // 2))
+    return y * gate
+
+
+def attention_embedding(sd: SD, x: torch.Tensor, calib: bool = False) -> torch.Tensor:
+    """`face_models.py:284-288`: features → attention → global average pool → B×512."""
+    f = resnet18_trunk(sd, "backbone.", x, pool=False, calib=calib)
+    if calib:
+        _alias_bn_stats(sd)
+    return attention_module(sd, "attention.", f).mean(dim=(2, 3))
+
+
+def attention_forward(sd: SD, x: torch.Tensor) -> torch.Tensor:
+    """`face_models.py:276-282`."""
+    return F.linear(attention_embedding(sd, x), sd["fc.weight"], sd["fc.bias"])
+
+
+def ensemble_combine(outputs: Sequence[torch.Tensor], method: str, weights: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`face_models.py:902-920`: how EnsembleModel merges its members' logits (a single member is returned as is;
+    any method but 'average' / 'weighted' / 'max' — including the constructor's 'attention' — raises ValueError)."""
+    outputs = list(outputs)
+    if len(outputs) == 1:
+        return outputs[0]
+    if method == "average":
+        return torch.mean(torch.stack(outputs), dim=0)
+    if method == "max":
+        probs = [F.softmax(o, dim=1) for o in outputs]
+        return torch.log(torch.max(torch.stack(probs), dim=0)[0])
+    if method == "weighted":
+        w = F.softmax(weights, dim=0)
+        return torch.sum(torch.stack([w[i] * outputs[i] for i in range(len(outputs))]), dim=0)
+    raise ValueError(f"Unknown ensemble method: {method}")
+
+
+# --------------------------------------------------------------------------------------------
 # a8  compare_faces   (src/app.py:50-64)      a11 class-centre match (hyperparameter_tuning.py:1036-1046)
 # --------------------------------------------------------------------------------------------
 def compare_faces(emb, refs: Sequence[dict], thresh: float):
@@ -279,11 +329,11 @@ def class_centre_match(emb: torch.Tensor, centres: torch.Tensor, s: float = 1.0)
 # --------------------------------------------------------------------------------------------
 # dispatch by reference model_type (face_models.py:785-813)
 # --------------------------------------------------------------------------------------------
-FORWARD = {"baseline": baseline_forward, "cnn": cnn_forward, "arcface": arcface_forward,
+FORWARD = {"attention": attention_forward, "baseline": baseline_forward, "cnn": cnn_forward, "arcface": arcface_forward,
            "hybrid": hybrid_forward}
-EMBEDDING = {"baseline": baseline_embedding, "cnn": cnn_embedding, "arcface": arcface_embedding,
+EMBEDDING = {"attention": attention_embedding, "baseline": baseline_embedding, "cnn": cnn_embedding, "arcface": arcface_embedding,
              "siamese": siamese_forward_one, "hybrid": hybrid_embedding}
-_CALIB = {"baseline": baseline_embedding, "cnn": cnn_embedding, "arcface": arcface_pre_norm,
+_CALIB = {"attention": attention_embedding, "baseline": baseline_embedding, "cnn": cnn_embedding, "arcface": arcface_pre_norm,
           "siamese": siamese_pre_norm, "hybrid": hybrid_embedding}
 
 

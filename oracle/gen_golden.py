@@ -40,9 +40,12 @@ def _np(t):
     return t.detach().cpu().numpy().astype(np.float32)
 
 
-def gen_models(ref):
-    key_table = {}
-    for mt in ("baseline", "cnn", "arcface", "siamese", "hybrid"):
+def gen_models(ref, only=None):
+    keys_path = os.path.join(GOLD, "state_dict_keys.json")
+    key_table = json.load(open(keys_path)) if (only and os.path.exists(keys_path)) else {}
+    for mt in ("baseline", "cnn", "arcface", "siamese", "hybrid", "attention"):
+        if only and mt not in only:
+            continue
         torch.manual_seed(0)
         model = ref.get_model(mt, NUM_CLASSES)
         shapes = {k: (tuple(v.shape), v.dtype) for k, v in model.state_dict().items()}
@@ -85,6 +88,34 @@ def gen_models(ref):
         np.savez_compressed(os.path.join(GOLD, f"{mt}.npz"), **out)
     with open(os.path.join(GOLD, "state_dict_keys.json"), "w") as f:
         json.dump(key_table, f, indent=0, sort_keys=True)
+
+
+def gen_ensemble(ref):
+    """EnsembleModel (`face_models.py:843-941`) on three small logit sets: the combination rules only (the members'
+    own forward passes are pinned by their model files)."""
+    B, C = 8, NUM_CLASSES
+    outs = [synth.randn(5001 + i, (B, C), tag="ensemble.logits") * (1.0 + i) for i in range(3)]
+    w = torch.tensor([0.2, -0.4, 0.9])
+
+    class _Fixed(torch.nn.Module):
+        def __init__(self, y):
+            super().__init__()
+            self.y = y
+
+        def forward(self, x):
+            return self.y
+
+    res = {"weights": _np(w)}
+    for i, o in enumerate(outs):
+        res[f"logits{i}"] = _np(o)
+    for method in ("average", "weighted", "max"):
+        ens = ref.EnsembleModel([_Fixed(o) for o in outs], ensemble_method=method)
+        with torch.no_grad():
+            ens.weights.copy_(w)
+            y = ens(torch.zeros(B, 3, 8, 8))
+        res[method] = _np(y)
+        assert (fo.ensemble_combine(outs, method, w) - y).abs().max().item() < 1e-6
+    np.savez_compressed(os.path.join(GOLD, "ensemble.npz"), **res)
 
 
 def gen_arcmargin(ref):
@@ -158,10 +189,14 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
     ref = ref_loader.load_reference()
-    gen_gallery()
-    gen_match()
-    gen_arcmargin(ref)
-    gen_models(ref)
+    only = set(sys.argv[1:])  # e.g. `gen_golden.py attention ensemble` regenerates just those files
+    if not only:
+        gen_gallery()
+        gen_match()
+        gen_arcmargin(ref)
+    if not only or "ensemble" in only:
+        gen_ensemble(ref)
+    gen_models(ref, only or None)
     print("golden vectors written to", GOLD)
 
 

@@ -22,7 +22,7 @@ from oracle import face_oracle  # noqa: E402
 
 # SURVEY.md §8d suggested seeds
 SEEDS = {"baseline": (1001, 2001, 3001), "cnn": (1002, 2002, 3002), "arcface": (1004, 2004, 3004),
-         "siamese": (1006, 2006, 3006), "hybrid": (1005, 2005, 3005)}
+         "siamese": (1006, 2006, 3006), "hybrid": (1005, 2005, 3005), "attention": (1007, 2007, 3007)}
 N_CALIB = 32
 N_GOLDEN = 16
 

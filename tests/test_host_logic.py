@@ -19,9 +19,13 @@ def test_get_model_types_and_errors():
     assert frmap_amd.MODEL_TYPES == ['baseline', 'cnn', 'siamese', 'attention', 'arcface', 'hybrid', 'ensemble']
     with pytest.raises(ValueError, match="Invalid model type"):       # face_models.py:813
         frmap_amd.get_model("nope")
-    for mt in ("attention", "ensemble"):
-        with pytest.raises(NotImplementedError):
-            frmap_amd.get_model(mt)
+    att = frmap_amd.get_model("attention", 36)                       # face_models.py:797-799
+    assert isinstance(att, frmap_amd.AttentionNet) and att.fc.out_features == 36
+    ens = frmap_amd.get_model("ensemble", 36)                        # face_models.py:805-808: cnn + attention + arcface, 'average'
+    assert [type(m).__name__ for m in ens.models] == ["ResNetTransfer", "AttentionNet", "ArcFaceNet"]
+    assert ens.ensemble_method == "average" and not ens.weights.requires_grad
+    ens2 = frmap_amd.get_model(["baseline", "cnn"], 36)               # face_models.py:809-811: a list builds an ensemble
+    assert len(ens2.models) == 2
     m = frmap_amd.get_model("arcface", 36)
     assert m.training and next(m.parameters()).device.type == "cpu" and next(m.parameters()).dtype == torch.float32
     with pytest.raises(ValueError, match="Labels must be provided during training"):   # face_models.py:528-529

@@ -36,7 +36,7 @@ def _centered_cos(a, b):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("mt", ["baseline", "cnn", "arcface", "siamese", "hybrid"])
+@pytest.mark.parametrize("mt", ["baseline", "cnn", "arcface", "siamese", "hybrid", "attention"])
 def test_model_parity(mt, dtype, gold_dir, calibrated_sd):
     z = np.load(os.path.join(gold_dir, f"{mt}.npz"))
     sd = calibrated_sd(mt)
@@ -79,6 +79,69 @@ def test_model_parity(mt, dtype, gold_dir, calibrated_sd):
             assert float((out - ref).norm() / ref.norm()) < tol["rel"]
             if mt == "cnn":
                 assert m.get_embedding(x[:1].to(DEV)).shape == (512,)       # the reference's .squeeze()
+
+
+def test_attention_map_and_kernel(calibrated_sd):
+    """frmap_cnn_attention against the oracle's AttentionModule on the same (storage-rounded) trunk map: the attended map
+    itself, not only its pooled embedding."""
+    from frmap_amd import ops
+    sd = calibrated_sd("attention")
+    x = weights.golden_inputs("attention")[:4]
+    m = _model("attention", sd, torch.float16)
+    with torch.no_grad():
+        amap = m.attention_map(x.to(DEV)).float().cpu().permute(0, 3, 1, 2)       # B×512×7×7
+        f = fo.resnet18_trunk(sd, "backbone.", x, pool=False)
+        ref = fo.attention_module(sd, "attention.", f)
+    assert amap.shape == ref.shape
+    rel = float((amap - ref).norm() / ref.norm())
+    print(f"attention map rel-L2 {rel:.2e}")
+    assert rel < 1.5e-2
+    assert m.get_attention_params()["gamma"] == pytest.approx(float(sd["attention.gamma"]))
+    # direct kernel call on a 5x5 map with 256 channels and a 3x3 gate (the non-default template paths)
+    B, H, W, C, Cq = 3, 5, 5, 256, 32
+    xm = synth.randn(71, (B, H, W, C), "xm").half()
+    qkv = (synth.randn(72, (B, H, W, 2 * Cq + C), "qkv") * 0.3).half()
+    gamma, sw, sb = torch.tensor([0.7]), synth.randn(73, (1, 2, 3, 3), "sw") * 0.3, torch.tensor([0.1])
+    om, op = ops.cnn_attention(qkv.to(DEV), xm.to(DEV), gamma.to(DEV), sw.to(DEV), sb.to(DEV), Cq, want_map=True)
+    q = qkv[..., :Cq].float().reshape(B, H * W, Cq)
+    k = qkv[..., Cq:2 * Cq].float().reshape(B, H * W, Cq)
+    v = qkv[..., 2 * Cq:].float().reshape(B, H * W, C)
+    att = torch.softmax(torch.bmm(q, k.transpose(1, 2)), dim=-1)
+    y = 0.7 * torch.bmm(att, v) + xm.float().reshape(B, H * W, C)
+    ymap = y.reshape(B, H, W, C).permute(0, 3, 1, 2)
+    pooled = torch.cat([ymap.mean(1, keepdim=True), ymap.max(1, keepdim=True)[0]], dim=1)
+    gate = torch.sigmoid(F.conv2d(pooled, sw, sb, padding=1))
+    want = (ymap * gate).permute(0, 2, 3, 1)
+    assert torch.allclose(om.float().cpu(), want, atol=2e-2, rtol=2e-3)
+    assert torch.allclose(op.cpu(), want.reshape(B, H * W, C).mean(1), atol=2e-3, rtol=2e-3)
+
+
+def test_ensemble_on_gpu(gold_dir, calibrated_sd):
+    """EnsembleModel (`face_models.py:843-941`): members run on the HIP path, the merge follows the reference's rules."""
+    members = []
+    for mt in ("cnn", "attention", "arcface"):
+        members.append(_model(mt, calibrated_sd(mt), torch.float16))
+    x = weights.golden_inputs("cnn")[:6]
+    with torch.no_grad():
+        logits = [fo.cnn_forward(calibrated_sd("cnn"), x), fo.attention_forward(calibrated_sd("attention"), x),
+                  F.linear(fo.arcface_embedding(calibrated_sd("arcface"), x), F.normalize(calibrated_sd("arcface")["arcface.weight"]))]
+    w = torch.tensor([0.3, -0.2, 0.8])
+    for method in ("average", "weighted", "max"):
+        ens = frmap_amd.EnsembleModel(members, ensemble_method=method).to(DEV).eval()
+        with torch.no_grad():
+            ens.weights.copy_(w.to(DEV))
+            out = ens(x.to(DEV)).float().cpu()
+        want = fo.ensemble_combine(logits, method, w)
+        assert out.shape == want.shape == (6, 36)
+        assert float((out - want).norm() / want.norm()) < 2e-2, method
+    ens = frmap_amd.EnsembleModel(members, ensemble_method="attention").to(DEV).eval()
+    with pytest.raises(ValueError, match="Unknown ensemble method"):
+        ens(x.to(DEV))
+    emb = frmap_amd.EnsembleModel(members, "average").to(DEV).eval().get_embedding(x.to(DEV))
+    assert emb.shape == (6, 512 * 3)                                   # concatenated member embeddings (:932-934)
+    single = frmap_amd.EnsembleModel(members[:1], "max").to(DEV).eval()
+    with torch.no_grad():
+        assert torch.equal(single(x.to(DEV)), members[0](x.to(DEV)))   # one valid member: returned as is (:902-904)
 
 
 def test_arcface_top1_identical_fp16(calibrated_sd):
