@@ -39,6 +39,10 @@ struct ConvParams {
   int ksplit;    // >1: the chunk loop is split over ksplit workgroups per tile, fp32 partials go to `slab`
   float* slab;   // [ksplit][M][Cout] fp32 partial sums (split-K only)
   int dbg;  // timing ablations only (FRMAP_CONV_DEBUG): 1 = stage chunk 0 only, 2 = skip the MFMA loop
+  // fused 1x1 projection shortcut (conv3x3_fast_kernel<TT, true>): out += W_ds . x_ds[n, oy*s, ox*s, :]
+  const void* ds_in;   // [N][ds_Hi][ds_Wi][ds_Cin]
+  const void* ds_w;    // packed like a 1x1 conv: [Cout/64][ds_Cin/32][1][64][4][8]
+  int ds_Hi, ds_Wi, ds_Cin, ds_stride, ds_chunks;
 };
 
 // 64 zero bytes: out-of-image (padding) pixels LOAD from here instead of branching around the load —
@@ -249,9 +253,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 //    scheduler sinks every ds_read to just before its use and each group of 4 MFMAs waits out an
 //    LDS round trip).  The 36 per-tap pixel addresses are recomputed (3 VALU ops, under the MFMAs).
 // ================================================================================================
-template <typename TT>
+// DS = true additionally folds a ResNet projection shortcut into the layer: out = act(conv3x3(in) + W_ds . x_ds(strided)
+// + shift), i.e. BasicBlock.conv2 + bn2 + downsample(conv1x1 s2 + bn) + add + ReLU in one launch.  The shortcut's K
+// dimension is run as extra one-tap stages after the first ds_chunks main chunks (<= nchunks of them): their 4
+// gathered-pixel pieces + 1 weight piece per thread are prefetched next to the main chunk's 19, written into the same
+// LDS images once the main chunk's MFMAs are done, and cost 16 MFMAs + two barriers each.  Saves the 1x1 launch, its
+// output round trip through HBM and the residual read.
+template <typename TT, bool DS>
 __global__ __launch_bounds__(256, 2) void conv3x3_fast_kernel(const ConvParams p) {
-  constexpr int MI = 4, NI = 4, TAPS = 9, NB = 10, NL = NB + TAPS, NG = TAPS * NI;
+  constexpr int MI = 4, NI = 4, TAPS = 9, NB = 10, ND = DS ? 5 : 0, NL = NB + TAPS + ND, NG = TAPS * NI;
   using vec8 = typename TT::vec8;
   using elem = typename TT::elem;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -306,20 +316,50 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fast_kernel(const ConvParams p
   };
   // piece j of a stage: j < NB halo pixels, then the 9 weight taps (already in LDS-image order)
   int pso = 0;  // scalar byte offset of the halo loads (the chunk's 32 channels)
+  // shortcut stage dc (DS): 256 gathered pixels x 32 channels (4 pieces per thread) + its 64 x 32 weight block (1 piece)
+  unsigned doff[DS ? 4 : 1];
+  u32x4_t dv[DS ? 4 : 1], dw = {0u, 0u, 0u, 0u};
+  __amdgpu_buffer_rsrc_t rs_dx = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, (short)0, 0, 0x00020000), rs_dw = rs_dx;
+  const elem* dbase = nullptr;
+  const char* dwbase = nullptr;
+  int rec_dx = 0;
   auto prefetch1 = [&](int chunk, int j) {
     if (j < NB) hv[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)soff[j], pso, 0);
-    else wv[j - NB] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, tid * 16, (chunk * TAPS + (j - NB)) * 4096, 0);
+    else if (j < NB + TAPS) wv[j - NB] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, tid * 16, (chunk * TAPS + (j - NB)) * 4096, 0);
+    else if (DS) {
+      // (chunk - 1 = the main chunk whose MFMAs these ride under = the shortcut stage they feed)
+      if (j < NB + TAPS + 4) dv[j - NB - TAPS] = __builtin_amdgcn_raw_buffer_load_b128(rs_dx, (int)doff[j - NB - TAPS], (chunk - 1) * 64, 0);
+      else dw = __builtin_amdgcn_raw_buffer_load_b128(rs_dw, tid * 16, (chunk - 1) * 4096, 0);
+    }
   };
 
   const int L = xcd_remap_fwd(blockIdx.x, gridDim.x);
   setup_load(L);
   set_rsrc(true);
 #pragma unroll
-  for (int j = 0; j < NL; ++j) prefetch1(0, j);
+  for (int j = 0; j < NB + TAPS; ++j) prefetch1(0, j);
 
   {
     const int mt = L / ntiles, nt = L - mt * ntiles;
     const int m0 = mt << 8;
+    if (DS) {
+      // gather sources: output pixel m -> shortcut input pixel (n, oy * s, ox * s), relative to the tile's first image
+      const int n0d = m0 / p.HoWo;
+      const size_t img = (size_t)p.ds_Hi * p.ds_Wi * p.ds_Cin;
+      const size_t remd = ((size_t)p.N - n0d) * img * sizeof(elem);
+      dbase = (const elem*)p.ds_in + (size_t)n0d * img;
+      rec_dx = (int)(remd < 0x7FFFFFFFull ? remd : 0x7FFFFFFFull);
+      dwbase = (const char*)p.ds_w + (size_t)nt * p.ds_chunks * 4096;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int px = (q * 256 + tid) >> 2, cg = tid & 3;
+        const int m = m0 + px;
+        const int n = m / p.HoWo, rem = m - n * p.HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        doff[q] = m < p.M ? (unsigned)((((n - n0d) * p.ds_Hi + oy * p.ds_stride) * p.ds_Wi + ox * p.ds_stride) * p.ds_Cin + cg * 8) *
+                                (unsigned)sizeof(elem)
+                          : 0xFFFFFF00u;
+      }
+    }
     int A[MI];  // (pixel index in the halo image) * 64 + k-group * 16, before the tap offset and the swizzle
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -347,7 +387,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fast_kernel(const ConvParams p
       const int pchunk = chunk + 1;
       pso = pchunk * 64;
       set_rsrc(pchunk < p.nchunks);
-      if (pchunk == p.nchunks && p.res) {
+      if (DS) {  // the shortcut pieces riding under this chunk feed shortcut stage `chunk`; past the last stage: empty descriptors
+        const bool dl = chunk < p.ds_chunks;
+        rs_dx = __builtin_amdgcn_make_buffer_rsrc((void*)dbase, (short)0, dl ? rec_dx : 0, 0x00020000);
+        rs_dw = __builtin_amdgcn_make_buffer_rsrc((void*)dwbase, (short)0, dl ? p.ds_chunks * 4096 : 0, 0x00020000);
+      }
+      if (!DS && pchunk == p.nchunks && p.res) {
         // last chunk: the idle prefetch slots fetch this thread's 8 residual pieces (the epilogue's layout),
         // so the residual tile lands under the MFMAs instead of being waited for in the epilogue
         pso = 0;
@@ -389,11 +434,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fast_kernel(const ConvParams p
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      if (DS && chunk < p.ds_chunks) {
+        // ---- shortcut stage `chunk`: its operands replace the main chunk's LDS images for 16 MFMAs
+        __syncthreads();
+        *(u32x4_t*)(wl + tid * 16) = dw;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(u32x4_t*)(halo + px_off<1>((q * 256 + tid) >> 2, tid & 3)) = dv[q];
+        __syncthreads();
+        vec8 wd[NI], pd[MI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) wd[ni] = *(const vec8*)(wl + ni * 1024 + woff);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) pd[mi] = *(const vec8*)(halo + px_off<1>(wave * 64 + mi * 16 + lr, g));
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = TT::mfma(wd[ni], pd[mi], acc[mi][ni]);
+      }
     }
     // ---- epilogue: + shift (+ residual) (activation) -> NHWC, whole-line 16-byte stores via an LDS transpose
     __syncthreads();  // every wave is done reading the staged tiles; LDS is free for the transpose
-    conv_epilogue<TT, MI, NI>(acc, smem + wave * (16 * (NI * 64 + 16)), m0 + wave * 64, p.M, p.Cout, nt << 6, p.shift,
-                              (const elem*)p.res, (elem*)p.out, p.relu, lane, hv);
+    if (DS)
+      conv_epilogue<TT, MI, NI>(acc, smem + wave * (16 * (NI * 64 + 16)), m0 + wave * 64, p.M, p.Cout, nt << 6, p.shift,
+                                (const elem*)nullptr, (elem*)p.out, p.relu, lane);
+    else
+      conv_epilogue<TT, MI, NI>(acc, smem + wave * (16 * (NI * 64 + 16)), m0 + wave * 64, p.M, p.Cout, nt << 6, p.shift,
+                                (const elem*)p.res, (elem*)p.out, p.relu, lane, hv);
   }
 }
 
@@ -1021,9 +1087,18 @@ static int launch(const ConvParams& p, int lds_bytes, hipStream_t st) {
   return 0;
 }
 
-extern "C" int frmap_conv_igemm(const void* in, const void* w_packed, const float* shift, const void* residual,
-                                void* out, int B, int Hi, int Wi, int Cin, int Cout, int K, int stride, int pad,
-                                int relu, int dtype, void* stream) {
+struct DsArgs {  // fused projection shortcut (conv3x3_fast_kernel<TT, true>); in == nullptr: none
+  const void* in;
+  const void* w;
+  int Hi, Wi, Cin, stride;
+};
+
+// does a 3x3 stride-1 layer (with this shortcut) take conv3x3_fast_kernel<TT, true>?
+static bool conv_ds_ok(int B, int Hi, int Wi, int Cin, int Cout, const DsArgs& d);
+
+static int conv_igemm_impl(const void* in, const void* w_packed, const float* shift, const void* residual,
+                           void* out, int B, int Hi, int Wi, int Cin, int Cout, int K, int stride, int pad,
+                           int relu, int dtype, const DsArgs& ds, void* stream) {
   FRMAP_REQUIRE(in && w_packed && shift && out, "conv_igemm: null pointer");
   FRMAP_REQUIRE(K == 1 || K == 3, "conv_igemm: kernel size %d not supported (1 or 3)", K);
   FRMAP_REQUIRE(stride == 1 || stride == 2, "conv_igemm: stride %d not supported", stride);
@@ -1047,6 +1122,10 @@ extern "C" int frmap_conv_igemm(const void* in, const void* w_packed, const floa
   p.nchunks = Cin / 32;
   p.ksplit = 1;
   p.slab = nullptr;
+  p.ds_in = ds.in; p.ds_w = ds.w; p.ds_Hi = ds.Hi; p.ds_Wi = ds.Wi; p.ds_Cin = ds.Cin; p.ds_stride = ds.stride;
+  p.ds_chunks = ds.in ? ds.Cin / 32 : 0;
+  if (ds.in) FRMAP_REQUIRE(conv_ds_ok(B, Hi, Wi, Cin, Cout, ds) && !residual && K == 3 && stride == 1,
+                           "conv_igemm_ds: this shape does not take the fused-shortcut kernel (check frmap_conv_igemm_ds_supported)");
   {
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("FRMAP_CONV_DEBUG"); dbg = e ? atoi(e) : 0; }
@@ -1130,7 +1209,7 @@ extern "C" int frmap_conv_igemm(const void* in, const void* w_packed, const floa
   {
     static int wres = -1;
     if (wres < 0) { const char* e = getenv("FRMAP_CONV_WRES"); wres = e ? atoi(e) : 1; }
-    if (wres && stride == 1 && p.dbg == 0 && Cin == 64 && Hi % 8 == 0 && Wi % 8 == 0 &&
+    if (wres && !ds.in && stride == 1 && p.dbg == 0 && Cin == 64 && Hi % 8 == 0 && Wi % 8 == 0 &&
         (long long)Hi * Wi * Cin * 2 < (1ll << 31) && (long long)8 * Wo * Cout * 2 < (1ll << 31)) {
       const int total = B * (Hi / 8) * (Wi / 8);
       int cus = 256;
@@ -1161,24 +1240,25 @@ extern "C" int frmap_conv_igemm(const void* in, const void* w_packed, const floa
       return 0;
     }
   }
+  if (ds.in) FRMAP_REQUIRE(fastk, "conv_igemm_ds: layer does not take the register-prefetch kernel");
   if (fastk) {
     const int grid = p.nblocks;
-    const void* kern = dtype == FRMAP_BF16 ? (const void*)conv3x3_fast_kernel<BF16> : (const void*)conv3x3_fast_kernel<F16>;
-    static bool attr[2] = {false, false};
-    if (!attr[dtype]) {
-      hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    typedef void (*kern_t)(const ConvParams);
+    static const kern_t kerns[4] = {conv3x3_fast_kernel<BF16, false>, conv3x3_fast_kernel<BF16, true>,
+                                    conv3x3_fast_kernel<F16, false>, conv3x3_fast_kernel<F16, true>};
+    const int ki = (dtype == FRMAP_BF16 ? 0 : 2) + (ds.in ? 1 : 0);
+    static bool attr[4] = {false, false, false, false};
+    if (!attr[ki]) {
+      hipError_t e = hipFuncSetAttribute((const void*)kerns[ki], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) {
         frmap_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
         return -2;
       }
-      attr[dtype] = true;
+      attr[ki] = true;
     }
     const int scratch = 4 * 16 * (4 * 64 + 16);
     const int ldsf = lds < scratch ? scratch : lds;
-    if (dtype == FRMAP_BF16)
-      hipLaunchKernelGGL(conv3x3_fast_kernel<BF16>, dim3(grid), dim3(256), ldsf, st, p);
-    else
-      hipLaunchKernelGGL(conv3x3_fast_kernel<F16>, dim3(grid), dim3(256), ldsf, st, p);
+    hipLaunchKernelGGL(kerns[ki], dim3(grid), dim3(256), ldsf, st, p);
     FRMAP_LAUNCH_CHECK();
     return 0;
   }
@@ -1187,6 +1267,42 @@ extern "C" int frmap_conv_igemm(const void* in, const void* w_packed, const floa
              : (stride == 1 ? launch<TT, 128, 3, 1>(p, lds, st) : launch<TT, 128, 3, 2>(p, lds, st)))
   return dtype == FRMAP_BF16 ? FRMAP_DISPATCH(BF16) : FRMAP_DISPATCH(F16);
 #undef FRMAP_DISPATCH
+}
+
+static bool conv_ds_ok(int B, int Hi, int Wi, int Cin, int Cout, const DsArgs& d) {
+  if (!d.in || !d.w || d.Cin <= 0 || d.Cin % 32 || d.Cin / 32 > Cin / 32 || d.stride < 1) return false;
+  if ((d.Hi - 1) / d.stride + 1 != Hi || (d.Wi - 1) / d.stride + 1 != Wi) return false;  // 1x1, pad 0: Ho = (H-1)/s + 1
+  const int Hp = Hi + 2, Wp = Wi + 2;
+  long long hb = (long long)halo_rows_bound(256, Hi, Wi, Hp, 1, 3) * Wp * 64;
+  hb = (hb + 1023) & ~1023ll;
+  const long long lds = hb + 9 * 4096;
+  return hb >= 256 * 64 && hb / 16 <= 10 * 256 && lds <= 80 * 1024 && hb / 64 < 65536 &&
+         (long long)(256 / (Hi * Wi) + 3) * Hi * Wi * Cin * 2 < (1ll << 31) &&
+         (long long)(256 / (Hi * Wi) + 3) * d.Hi * d.Wi * d.Cin * 2 < (1ll << 31);
+}
+
+extern "C" int frmap_conv_igemm(const void* in, const void* w_packed, const float* shift, const void* residual,
+                                void* out, int B, int Hi, int Wi, int Cin, int Cout, int K, int stride, int pad,
+                                int relu, int dtype, void* stream) {
+  const DsArgs none = {nullptr, nullptr, 0, 0, 0, 0};
+  return conv_igemm_impl(in, w_packed, shift, residual, out, B, Hi, Wi, Cin, Cout, K, stride, pad, relu, dtype, none, stream);
+}
+
+extern "C" int frmap_conv_igemm_ds_supported(int B, int Hi, int Wi, int Cin, int Cout, int ds_Hi, int ds_Wi, int ds_Cin,
+                                             int ds_stride) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("FRMAP_CONV_DSFUSE"); on = e ? atoi(e) : 1; }
+  if (!on || B <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cin % 32 || Cout <= 0 || Cout % 64) return 0;
+  const DsArgs d = {(const void*)1, (const void*)1, ds_Hi, ds_Wi, ds_Cin, ds_stride};
+  return conv_ds_ok(B, Hi, Wi, Cin, Cout, d) ? 1 : 0;
+}
+
+extern "C" int frmap_conv_igemm_ds(const void* in, const void* w_packed, const float* shift, const void* ds_in,
+                                   const void* ds_w_packed, void* out, int B, int Hi, int Wi, int Cin, int Cout,
+                                   int ds_Hi, int ds_Wi, int ds_Cin, int ds_stride, int relu, int dtype, void* stream) {
+  FRMAP_REQUIRE(ds_in && ds_w_packed, "conv_igemm_ds: null shortcut pointer");
+  const DsArgs d = {ds_in, ds_w_packed, ds_Hi, ds_Wi, ds_Cin, ds_stride};
+  return conv_igemm_impl(in, w_packed, shift, nullptr, out, B, Hi, Wi, Cin, Cout, 3, 1, 1, relu, dtype, d, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

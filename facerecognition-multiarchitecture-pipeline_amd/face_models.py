@@ -206,8 +206,16 @@ class _TrunkPlan:
         else:  # wider than the fused kernel's 8 column strips
             x = ops.maxpool(self.stem(ops.pack_input(x, self.dtype), relu=True), 3, 2, 1)
         for c1, c2, ds in self.blocks:
-            idn = ds(x, relu=False) if ds is not None else x
-            x = c2(c1(x, relu=True), relu=True, residual=idn)
+            if ds is None:
+                x = c2(c1(x, relu=True), relu=True, residual=x)
+                continue
+            h = c1(x, relu=True)
+            B, Hh, Wh, Ch = h.shape
+            if ds.k == 1 and ops.conv_ds_supported(B, Hh, Wh, Ch, c2.cout, x.shape[1], x.shape[2], x.shape[3], ds.stride):
+                # conv2 + bn2 + projection shortcut + add + ReLU in one launch (the shortcut as extra K stages)
+                x = ops.conv_igemm_ds(h, c2.wpk, c2.shift + ds.shift, c2.cout, x, ds.wpk, ds.stride, True)
+            else:
+                x = c2(h, relu=True, residual=ds(x, relu=False))
         return x
 
     def pooled(self, x: torch.Tensor) -> torch.Tensor:

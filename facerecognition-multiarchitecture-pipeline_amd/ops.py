@@ -134,6 +134,37 @@ def conv_igemm(x: torch.Tensor, wpk: torch.Tensor, shift: torch.Tensor, Cout: in
     return out
 
 
+_ds_ok_cache: dict = {}
+
+
+def conv_ds_supported(B: int, H: int, W: int, Cin: int, Cout: int, dsH: int, dsW: int, dsCin: int, ds_stride: int) -> bool:
+    key = (B, H, W, Cin, Cout, dsH, dsW, dsCin, ds_stride)
+    v = _ds_ok_cache.get(key)
+    if v is None:
+        v = _ds_ok_cache[key] = bool(_lib.load().frmap_conv_igemm_ds_supported(*key))
+    return v
+
+
+def conv_igemm_ds(x: torch.Tensor, wpk: torch.Tensor, shift: torch.Tensor, Cout: int, x_ds: torch.Tensor, wpk_ds: torch.Tensor,
+                  ds_stride: int, relu) -> torch.Tensor:
+    """``act(conv3x3_s1_p1(x) + conv1x1_stride(x_ds) + shift)`` — a BasicBlock's second conv with its projection
+    shortcut folded in (``shift`` = both folded BatchNorm shifts added).  Check ``conv_ds_supported`` first."""
+    x = _dev(x, "conv_igemm_ds.x")
+    x_ds = _dev(x_ds, "conv_igemm_ds.x_ds", x.dtype)
+    B, H, W, Cin = x.shape
+    Bd, Hd, Wd, Cd = x_ds.shape
+    if Bd != B or wpk.numel() != Cout * Cin * 9 or wpk_ds.numel() != Cout * Cd or wpk.dtype != x.dtype or wpk_ds.dtype != x.dtype:
+        raise ValueError("conv_igemm_ds: operand shapes / dtypes do not match")
+    if shift.numel() != Cout:
+        raise ValueError("conv_igemm_ds: shift must have Cout elements")
+    out = torch.empty((B, H, W, Cout), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().frmap_conv_igemm_ds(x.data_ptr(), _dev(wpk, "wpk").data_ptr(),
+                                               _dev(shift, "shift", torch.float32).data_ptr(), x_ds.data_ptr(),
+                                               _dev(wpk_ds, "wpk_ds").data_ptr(), out.data_ptr(), B, H, W, Cin, Cout,
+                                               Hd, Wd, Cd, ds_stride, int(relu), dt_code(x.dtype), _stream()), "conv_igemm_ds")
+    return out
+
+
 def linear_mfma(x2d: torch.Tensor, wpk: torch.Tensor, shift: torch.Tensor, N: int, act=0,
                 residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``act(x · Wᵀ + shift [+ residual])`` on the MFMA conv kernel (split-K when the output is small)."""

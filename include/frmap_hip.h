@@ -107,6 +107,21 @@ int frmap_conv_igemm(const void* in, const void* w_packed, const float* shift, c
                      void* out, int B, int Hi, int Wi, int Cin, int Cout, int K, int stride, int pad,
                      int relu, int dtype, void* stream);
 
+/* A 3x3 stride-1 pad-1 convolution with a ResNet projection shortcut folded in (BasicBlock.conv2 + bn2 + downsample
+ * [conv1x1 stride s + bn] + add + ReLU of the first block of a stage, torchvision resnet.py via face_models.py:67):
+ *   out = act( conv3x3(in, W) + conv1x1_stride_s(ds_in, W_ds) + shift ),   shift = shift_conv + shift_shortcut
+ *   in        : B×Hi×Wi×Cin;  ds_in : B×ds_Hi×ds_Wi×ds_Cin with (ds_H - 1)/s + 1 == Hi (the block's input)
+ *   w_packed  : frmap_pack_conv_weight(W [Cout][Cin][3][3]);  ds_w_packed : frmap_pack_conv_weight(W_ds [Cout][ds_Cin][1][1])
+ * The shortcut runs as extra one-tap K stages of the same kernel: no 1x1 launch, no round trip of its output through
+ * HBM, no residual read.  frmap_conv_igemm_ds_supported(...) != 0 tells whether a shape takes this kernel (3x3 s1 layers
+ * of the register-prefetch kind with ds_Cin <= Cin); otherwise run the shortcut with frmap_conv_igemm and pass it as
+ * `residual`. */
+int frmap_conv_igemm_ds_supported(int B, int Hi, int Wi, int Cin, int Cout, int ds_Hi, int ds_Wi, int ds_Cin,
+                                  int ds_stride);
+int frmap_conv_igemm_ds(const void* in, const void* w_packed, const float* shift, const void* ds_in,
+                        const void* ds_w_packed, void* out, int B, int Hi, int Wi, int Cin, int Cout,
+                        int ds_Hi, int ds_Wi, int ds_Cin, int ds_stride, int relu, int dtype, void* stream);
+
 /* Wide Linear (+folded BatchNorm1d) (+ReLU/GELU `act` as above) (+residual) on the same MFMA kernel:
  *   out[M][N] = act( x[M][K] · Wᵀ + shift [+ residual] ),  x / residual / out in `dtype`, w_packed from
  *   frmap_pack_conv_weight(W as [N][K][1][1]).  When the output has too few tiles to fill the GPU the K

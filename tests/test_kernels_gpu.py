@@ -26,6 +26,34 @@ def _tol(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,Cin,Cout,dsC,s", [
+    (3, 28, 28, 128, 128, 64, 2),      # layer2.0: conv2 + downsample(56x56x64, stride 2)
+    (5, 14, 14, 256, 256, 128, 2),     # layer3.0
+    (9, 7, 7, 512, 512, 256, 2),       # layer4.0: many images per tile, 8 shortcut stages
+    (2, 14, 14, 128, 64, 128, 1),      # stride-1 projection (ds_Cin == Cin: a shortcut stage after every main chunk)
+])
+def test_conv_igemm_fused_shortcut(dtype, B, H, W, Cin, Cout, dsC, s):
+    """frmap_conv_igemm_ds == conv3x3(h) + conv1x1_stride(x) + shift, ReLU (torchvision BasicBlock with downsample)."""
+    h = synth.randn(21, (B, Cin, H, W), "h").to(dtype)
+    xd = synth.randn(22, (B, dsC, (H - 1) * s + 1 + (s - 1), (W - 1) * s + 1 + (s - 1)), "xd").to(dtype)
+    w = (synth.randn(23, (Cout, Cin, 3, 3), "w") * math.sqrt(2.0 / (Cin * 9))).to(dtype)
+    wd = (synth.randn(24, (Cout, dsC, 1, 1), "wd") * math.sqrt(1.0 / dsC)).to(dtype)
+    shift = synth.randn(25, (Cout,), "b") * 0.1
+    ref = F.relu(F.conv2d(h.float(), w.float(), None, padding=1) + F.conv2d(xd.float(), wd.float(), None, stride=s)
+                 + shift.view(1, -1, 1, 1))
+    assert ops.conv_ds_supported(B, H, W, Cin, Cout, xd.shape[2], xd.shape[3], dsC, s)
+    y = ops.conv_igemm_ds(_nhwc(h).to(DEV), ops.pack_conv_weight(w.float().to(DEV), dtype), shift.to(DEV), Cout,
+                          _nhwc(xd).to(DEV), ops.pack_conv_weight(wd.float().to(DEV), dtype), s, True)
+    y = y.float().cpu().permute(0, 3, 1, 2)
+    atol, rtol = _tol(dtype)
+    assert y.shape == ref.shape
+    assert torch.allclose(y, ref, atol=atol, rtol=rtol), (y - ref).abs().max()
+    # shapes the fused kernel does not take are reported, not run
+    assert not ops.conv_ds_supported(B, H, W, Cin, Cout, xd.shape[2], xd.shape[3], 2 * Cin, s)   # more shortcut stages than main chunks
+    assert not ops.conv_ds_supported(B, H, W, Cin, Cout, xd.shape[2] + 4, xd.shape[3], dsC, s)    # geometry mismatch
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,res,relu", [
     (2, 56, 56, 64, 64, 3, 1, True, True),       # resnet layer1 (wave-autonomous weights-resident kernel)
     (3, 16, 24, 64, 128, 3, 1, True, True),      # same kernel: 2 channel tiles, 18 patches (fewer than waves)
