@@ -197,7 +197,10 @@ class _TrunkPlan:
         for li in range(1, 5):
             for blk in getattr(rn, f"layer{li}"):
                 ds = _PackedConv(blk.downsample[0], blk.downsample[1], dtype) if blk.downsample is not None else None
-                self.blocks.append((_PackedConv(blk.conv1, blk.bn1, dtype), _PackedConv(blk.conv2, blk.bn2, dtype), ds))
+                c2 = _PackedConv(blk.conv2, blk.bn2, dtype)
+                # (shift of the fused conv2 + shortcut launch: both folded BatchNorm shifts)
+                fshift = (c2.shift + ds.shift).contiguous() if ds is not None else None
+                self.blocks.append((_PackedConv(blk.conv1, blk.bn1, dtype), c2, ds, fshift))
 
     def features(self, x: torch.Tensor) -> torch.Tensor:
         """fp32 NCHW → NHWC B×7×7×512 (for 224² input) in the compute dtype."""
@@ -205,7 +208,7 @@ class _TrunkPlan:
             x = ops.stem7x7_maxpool(x, self.stem.wpk, self.stem.shift, self.dtype)   # fused stem, one kernel
         else:  # wider than the fused kernel's 8 column strips
             x = ops.maxpool(self.stem(ops.pack_input(x, self.dtype), relu=True), 3, 2, 1)
-        for c1, c2, ds in self.blocks:
+        for c1, c2, ds, fshift in self.blocks:
             if ds is None:
                 x = c2(c1(x, relu=True), relu=True, residual=x)
                 continue
@@ -213,7 +216,7 @@ class _TrunkPlan:
             B, Hh, Wh, Ch = h.shape
             if ds.k == 1 and ops.conv_ds_supported(B, Hh, Wh, Ch, c2.cout, x.shape[1], x.shape[2], x.shape[3], ds.stride):
                 # conv2 + bn2 + projection shortcut + add + ReLU in one launch (the shortcut as extra K stages)
-                x = ops.conv_igemm_ds(h, c2.wpk, c2.shift + ds.shift, c2.cout, x, ds.wpk, ds.stride, True)
+                x = ops.conv_igemm_ds(h, c2.wpk, fshift, c2.cout, x, ds.wpk, ds.stride, True)
             else:
                 x = c2(h, relu=True, residual=ds(x, relu=False))
         return x
