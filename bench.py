@@ -36,7 +36,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/fp16, MI355X_MICROARCH.md
-DOMINANT = "conv3x3_fast_kernel<BF16>"
+DOMINANT = "conv3x3_fast_kernel<BF16, false>"
 
 
 def _pmc_traffic(kernel, args, dtype):
