@@ -33,6 +33,7 @@ struct ConvParams {
   int stride, pad, relu;
   int M, HoWo, Hp, Wp;
   uint32_t magic_Wp, magic_Hp;
+  FrmapDiv dHoWo, dWo;  // exact divisions of pixel indices < 2^31 by HoWo / Wo (frmap_div)
   int nchunks;
   int halo_bytes;
   int nblocks;
@@ -95,11 +96,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   // origin of this tile in the "virtual padded row stack": padded row index G = n*Hp + iy + pad.
   int n0 = 0, rr0 = 0, nrows = 0;
   if (KS > 1) {
-    n0 = m0 / p.HoWo;
-    const int oy0 = (m0 - n0 * p.HoWo) / p.Wo;
+    n0 = frmap_div(m0, p.dHoWo);
+    const int oy0 = frmap_div(m0 - n0 * p.HoWo, p.dWo);
     rr0 = oy0 * p.stride;
-    const int n1 = mlast / p.HoWo;
-    const int oy1 = (mlast - n1 * p.HoWo) / p.Wo;
+    const int n1 = frmap_div(mlast, p.dHoWo);
+    const int oy1 = frmap_div(mlast - n1 * p.HoWo, p.dWo);
     nrows = (n1 - n0) * p.Hp + oy1 * p.stride - rr0 + KS;
   }
 
@@ -112,9 +113,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     if (KS == 1) {
       qb = m - m0;
     } else {
-      const int n = m / p.HoWo;
+      const int n = frmap_div(m, p.dHoWo);
       const int rem = m - n * p.HoWo;
-      const int oy = rem / p.Wo;
+      const int oy = frmap_div(rem, p.dWo);
       const int ox = rem - oy * p.Wo;
       qb = ((n - n0) * p.Hp + oy * p.stride - rr0) * p.Wp + ox * p.stride;
     }
@@ -131,9 +132,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     for (int it = 0; it < BM * 4 / 256; ++it) {
       const int px = (it * 256 + tid) >> 2;
       const int m = min(m0 + px, p.M - 1);
-      const int n = m / p.HoWo;
+      const int n = frmap_div(m, p.dHoWo);
       const int rem = m - n * p.HoWo;
-      const int oy = rem / p.Wo;
+      const int oy = frmap_div(rem, p.dWo);
       const int ox = rem - oy * p.Wo;
       gsrc[it] = (((size_t)n * p.Hi + (size_t)(oy * p.stride)) * p.Wi + (size_t)(ox * p.stride)) * p.Cin +
                  (size_t)((tid & 3) * 8);
@@ -285,8 +286,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fast_kernel(const ConvParams p
   auto setup_load = [&](int L) {
     const int mt = L / ntiles, nt = L - mt * ntiles;
     const int m0 = mt << 8, mlast = min(m0 + 256, p.M) - 1;
-    const int n0 = m0 / p.HoWo, oy0 = (m0 - n0 * p.HoWo) / p.Wo;
-    const int n1 = mlast / p.HoWo, oy1 = (mlast - n1 * p.HoWo) / p.Wo;
+    const int n0 = frmap_div(m0, p.dHoWo), oy0 = frmap_div(m0 - n0 * p.HoWo, p.dWo);
+    const int n1 = frmap_div(mlast, p.dHoWo), oy1 = frmap_div(mlast - n1 * p.HoWo, p.dWo);
     const int nrows = (n1 - n0) * p.Hp + oy1 - oy0 + 3;
     l_nitems = nrows * p.Wp * 4; l_n0 = n0; l_rr0 = oy0;
     const size_t base_el = (size_t)n0 * p.Hi * p.Wi * p.Cin;  // image n0: tile-relative byte offsets fit 31 bits
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fast_kernel(const ConvParams p
     const int m0 = mt << 8;
     if (DS) {
       // gather sources: output pixel m -> shortcut input pixel (n, oy * s, ox * s), relative to the tile's first image
-      const int n0d = m0 / p.HoWo;
+      const int n0d = frmap_div(m0, p.dHoWo);
       const size_t img = (size_t)p.ds_Hi * p.ds_Wi * p.ds_Cin;
       const size_t remd = ((size_t)p.N - n0d) * img * sizeof(elem);
       dbase = (const elem*)p.ds_in + (size_t)n0d * img;
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fast_kernel(const ConvParams p
       for (int q = 0; q < 4; ++q) {
         const int px = (q * 256 + tid) >> 2, cg = tid & 3;
         const int m = m0 + px;
-        const int n = m / p.HoWo, rem = m - n * p.HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const int n = frmap_div(m, p.dHoWo), rem = m - n * p.HoWo, oy = frmap_div(rem, p.dWo), ox = rem - oy * p.Wo;
         doff[q] = m < p.M ? (unsigned)((((n - n0d) * p.ds_Hi + oy * p.ds_stride) * p.ds_Wi + ox * p.ds_stride) * p.ds_Cin + cg * 8) *
                                 (unsigned)sizeof(elem)
                           : 0xFFFFFF00u;
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fast_kernel(const ConvParams p
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int m = min(m0 + wave * 64 + mi * 16 + lr, p.M - 1);
-      const int n = m / p.HoWo, rem = m - n * p.HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      const int n = frmap_div(m, p.dHoWo), rem = m - n * p.HoWo, oy = frmap_div(rem, p.dWo), ox = rem - oy * p.Wo;
       A[mi] = ((((n - l_n0) * p.Hp + oy - l_rr0) * p.Wp + ox) << 6) | (g << 4);
     }
     f32x4_t acc[MI][NI];
@@ -689,8 +690,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_split_kernel(const ConvParam
   const int mt = L / ntiles, nt = L - mt * ntiles;
   const int m0 = mt * BM, mlast = min(m0 + BM, p.M) - 1;
   const int Hh = p.Hp >> 1;  // padded rows per image and parity
-  const int n0 = m0 / p.HoWo, oy0 = (m0 - n0 * p.HoWo) / p.Wo;
-  const int n1 = mlast / p.HoWo, oy1 = (mlast - n1 * p.HoWo) / p.Wo;
+  const int n0 = frmap_div(m0, p.dHoWo), oy0 = frmap_div(m0 - n0 * p.HoWo, p.dWo);
+  const int n1 = frmap_div(mlast, p.dHoWo), oy1 = frmap_div(mlast - n1 * p.HoWo, p.dWo);
   const int span = (n1 - n0) * Hh + oy1 - oy0;  // last pixel's row index within a parity plane
   const int rr0 = 2 * oy0;                       // padded row of the tile's first even row
 
@@ -698,7 +699,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_split_kernel(const ConvParam
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = min(m0 + wave * 64 + mi * 16 + lr, p.M - 1);
-    const int n = m / p.HoWo, rem = m - n * p.HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const int n = frmap_div(m, p.dHoWo), rem = m - n * p.HoWo, oy = frmap_div(rem, p.dWo), ox = rem - oy * p.Wo;
     qb[mi] = ((n - n0) * Hh + oy - oy0) * p.Wp + 2 * ox;
   }
   const int woff = (lr << 6) + ((g ^ (((lr >> 2) & 1) << 1)) << 4);
@@ -797,8 +798,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_fast_kernel(const ConvParams
   const int mt = L / ntiles, nt = L - mt * ntiles;
   const int m0 = mt << 8, mlast = min(m0 + 256, p.M) - 1;
   const int Hh = p.Hp >> 1;  // padded rows per image and parity
-  const int n0 = m0 / p.HoWo, oy0 = (m0 - n0 * p.HoWo) / p.Wo;
-  const int n1 = mlast / p.HoWo, oy1 = (mlast - n1 * p.HoWo) / p.Wo;
+  const int n0 = frmap_div(m0, p.dHoWo), oy0 = frmap_div(m0 - n0 * p.HoWo, p.dWo);
+  const int n1 = frmap_div(mlast, p.dHoWo), oy1 = frmap_div(mlast - n1 * p.HoWo, p.dWo);
   const int span = (n1 - n0) * Hh + oy1 - oy0;  // last pixel's row index within a parity plane
   const int rr0 = 2 * oy0;                       // padded row of the tile's first even row
   const int woff = (lr << 6) + ((g ^ (((lr >> 2) & 1) << 1)) << 4);
@@ -808,7 +809,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_fast_kernel(const ConvParams
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = min(m0 + wave * 64 + mi * 16 + lr, p.M - 1);
-    const int n = m / p.HoWo, rem = m - n * p.HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const int n = frmap_div(m, p.dHoWo), rem = m - n * p.HoWo, oy = frmap_div(rem, p.dWo), ox = rem - oy * p.Wo;
     A[mi] = ((((n - n0) * Hh + oy - oy0) * p.Wp + 2 * ox) << 6) | (g << 4);
   }
 
@@ -962,7 +963,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const ConvParams p) {
   for (int it = 0; it < NIT; ++it) {
     const int px = (it * 256 + tid) >> 2;
     const int m = min(m0 + px, p.M - 1);
-    const int n = m / p.HoWo, rem = m - n * p.HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const int n = frmap_div(m, p.dHoWo), rem = m - n * p.HoWo, oy = frmap_div(rem, p.dWo), ox = rem - oy * p.Wo;
     gsrc[it] = (((size_t)n * p.Hi + (size_t)(oy * p.stride)) * p.Wi + (size_t)(ox * p.stride)) * p.Cin + (size_t)((tid & 3) * 8);
   }
   int poff[MI];
@@ -1119,6 +1120,7 @@ static int conv_igemm_impl(const void* in, const void* w_packed, const float* sh
   p.stride = stride; p.pad = pad; p.relu = relu;
   p.M = (int)Mll; p.HoWo = Ho * Wo; p.Hp = Hi + 2 * pad; p.Wp = Wi + 2 * pad;
   p.magic_Wp = frmap_magic((uint32_t)p.Wp); p.magic_Hp = frmap_magic((uint32_t)p.Hp);
+  p.dHoWo = frmap_div_make((uint32_t)p.HoWo); p.dWo = frmap_div_make((uint32_t)p.Wo);
   p.nchunks = Cin / 32;
   p.ksplit = 1;
   p.slab = nullptr;
@@ -1368,6 +1370,7 @@ extern "C" int frmap_linear_mfma(const void* x, const void* w_packed, const floa
   p.stride = 1; p.pad = 0; p.relu = 0;
   p.M = M; p.HoWo = 1; p.Hp = 1; p.Wp = 1;
   p.magic_Wp = frmap_magic(1u); p.magic_Hp = frmap_magic(1u);
+  p.dHoWo = frmap_div_make(1u); p.dWo = frmap_div_make(1u);
   p.nchunks = K / 32; p.ksplit = ks; p.slab = (float*)workspace; p.dbg = 0;
   p.halo_bytes = 256 * 64;
   p.nblocks = ((M + 255) / 256) * (N / 64) * ks;

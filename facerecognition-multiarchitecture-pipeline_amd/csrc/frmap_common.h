@@ -178,6 +178,24 @@ __host__ __device__ inline uint32_t frmap_magic(uint32_t d) {
 }
 __device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t magic) { return __umulhi(n, magic); }
 
+// exact floor(n / d) for 0 <= n < 2^31 and a run-time d >= 1 prepared on the host: a hardware-less integer division
+// costs ~35 VALU instructions, this one a mul_hi and a shift.  d >= 2: k = ceil(log2 d), m = ceil(2^(31+k) / d) < 2^32,
+// q = (n * m) >> (31 + k) = mul_hi(n, m) >> (k - 1)  (error term m*d - 2^(31+k) < d <= 2^k keeps it exact for n < 2^31).
+struct FrmapDiv {
+  uint32_t m;  // 0: d == 1
+  uint32_t sh;
+};
+__host__ inline FrmapDiv frmap_div_make(uint32_t d) {
+  FrmapDiv r = {0u, 0u};
+  if (d <= 1) return r;
+  uint32_t k = 0;
+  while ((1ull << k) < d) ++k;
+  r.m = (uint32_t)((((unsigned long long)1 << (31 + k)) + d - 1) / d);
+  r.sh = k - 1;
+  return r;
+}
+__device__ __forceinline__ int frmap_div(int n, FrmapDiv d) { return d.m ? (int)(__umulhi((uint32_t)n, d.m) >> d.sh) : n; }
+
 // host-side error plumbing
 void frmap_set_error(const char* fmt, ...);
 #define FRMAP_REQUIRE(cond, ...)        \
