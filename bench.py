@@ -56,8 +56,8 @@ def _pmc_traffic(kernel, args, dtype):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="faces per GPU per step")
     ap.add_argument("--gallery", type=int, default=36)
     ap.add_argument("--model", default="cnn", choices=["cnn", "arcface", "baseline", "siamese", "hybrid", "attention"])
