@@ -353,6 +353,52 @@ def test_conv_igemm_random_geometries():
         assert torch.allclose(y, ref, atol=atol, rtol=rtol), (case, B, H, W, Cin, Cout, k, s_, float((y - ref).abs().max()))
 
 
+def test_conv_wave_and_shortcut_random_geometries():
+    """Seeded random shapes for the two newest kernels: the wave-autonomous Cin=64 kernel (H, W multiples of 8, 1-3
+    channel tiles, with/without residual and activation incl. GELU) and the fused projection shortcut."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    for case in range(16):
+        dtype = DTYPES[case % 2]
+        B = int(rng.integers(1, 7))
+        H, W = 8 * int(rng.integers(1, 6)), 8 * int(rng.integers(1, 6))
+        Cout = int(rng.choice([64, 128, 192]))
+        act, res = int(rng.integers(0, 3)), bool(rng.integers(0, 2))
+        x = synth.randn(7000 + case, (B, 64, H, W), "x").to(dtype)
+        w = (synth.randn(7100 + case, (Cout, 64, 3, 3), "w") * math.sqrt(2.0 / 576)).to(dtype)
+        shift = synth.randn(7200 + case, (Cout,), "b") * 0.1
+        ref = F.conv2d(x.float(), w.float(), None, padding=1) + shift.view(1, -1, 1, 1)
+        r = synth.randn(7300 + case, tuple(ref.shape), "r").to(dtype) if res else None
+        if res:
+            ref = ref + r.float()
+        ref = F.relu(ref) if act == 1 else (F.gelu(ref) if act == 2 else ref)
+        y = ops.conv_igemm(_nhwc(x).to(DEV), ops.pack_conv_weight(w.float().to(DEV), dtype), shift.to(DEV), Cout, 3, 1, 1, act,
+                           _nhwc(r).to(DEV) if res else None).float().cpu().permute(0, 3, 1, 2)
+        atol, rtol = _tol(dtype)
+        assert torch.allclose(y, ref, atol=atol, rtol=rtol), ("wave", case, B, H, W, Cout, act, res, float((y - ref).abs().max()))
+    for case in range(12):
+        dtype = DTYPES[case % 2]
+        B = int(rng.integers(1, 6))
+        H, W = int(rng.integers(3, 30)), int(rng.integers(3, 30))
+        Cin = int(rng.choice([64, 96, 128]))
+        dsC = int(rng.choice([c for c in (32, 64, 96, 128) if c <= Cin]))
+        Cout, s_ = int(rng.choice([64, 128])), int(rng.choice([1, 2]))
+        Hd, Wd = (H - 1) * s_ + 1 + int(rng.integers(0, s_)), (W - 1) * s_ + 1 + int(rng.integers(0, s_))
+        if not ops.conv_ds_supported(B, H, W, Cin, Cout, Hd, Wd, dsC, s_):
+            continue
+        h = synth.randn(8000 + case, (B, Cin, H, W), "h").to(dtype)
+        xd = synth.randn(8100 + case, (B, dsC, Hd, Wd), "xd").to(dtype)
+        w = (synth.randn(8200 + case, (Cout, Cin, 3, 3), "w") * math.sqrt(2.0 / (Cin * 9))).to(dtype)
+        wd = (synth.randn(8300 + case, (Cout, dsC, 1, 1), "wd") * math.sqrt(1.0 / dsC)).to(dtype)
+        shift = synth.randn(8400 + case, (Cout,), "b") * 0.1
+        ref = F.relu(F.conv2d(h.float(), w.float(), None, padding=1) + F.conv2d(xd.float(), wd.float(), None, stride=s_)
+                     + shift.view(1, -1, 1, 1))
+        y = ops.conv_igemm_ds(_nhwc(h).to(DEV), ops.pack_conv_weight(w.float().to(DEV), dtype), shift.to(DEV), Cout,
+                              _nhwc(xd).to(DEV), ops.pack_conv_weight(wd.float().to(DEV), dtype), s_, True)
+        y = y.float().cpu().permute(0, 3, 1, 2)
+        atol, rtol = _tol(dtype)
+        assert torch.allclose(y, ref, atol=atol, rtol=rtol), ("ds", case, B, H, W, Cin, dsC, Cout, s_, float((y - ref).abs().max()))
+
+
 def test_rejections_do_not_launch():
     with pytest.raises(ValueError):
         ops.conv_igemm(torch.zeros(1, 8, 8, 48, device=DEV, dtype=torch.float16),
