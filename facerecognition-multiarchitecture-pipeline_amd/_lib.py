@@ -52,6 +52,7 @@ PROTOTYPES = {
     "frmap_pairwise_distance": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
     "frmap_head_workspace_bytes": (_sz, [_i, _i]),
     "frmap_match_top1": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
+    "frmap_gap_norm_match": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _f, _i, _i, _i, _i, _i, _vp]),
     "frmap_cosine_logits": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "frmap_arcmargin_eval": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
 }

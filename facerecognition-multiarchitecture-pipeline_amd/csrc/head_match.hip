@@ -319,6 +319,124 @@ __global__ __launch_bounds__(256) void match_small_kernel(const float* __restric
   }
 }
 
+// The whole tail of the ResNet-18 ('cnn') embed-and-match step for small galleries in one launch, one workgroup
+// per face: AdaptiveAvgPool2d(1) of the trunk map (face_models.py:100) -> (optional) F.normalize -> the
+// compare_faces scan of match_small_kernel.  Replaces avgpool_global + l2_normalize + match_small (3 launches
+// of 5-12 us that are pure latency at 256 faces); the embedding only passes through LDS.
+template <typename TT>
+__global__ __launch_bounds__(256) void gap_norm_match_kernel(const typename TT::elem* __restrict__ map, const float* __restrict__ gal,
+                                                             float* __restrict__ emb_out, int32_t* __restrict__ idx_out,
+                                                             float* __restrict__ dist_out, int32_t* __restrict__ id_thr_out,
+                                                             int32_t* __restrict__ packed_out, float thresh, int normalize,
+                                                             float eps, int HW, int C, int G) {
+  extern __shared__ float s_e[];  // [C] embedding, then 4 + 4 reduction slots
+  float* s_red = s_e + C;
+  int* s_idx = (int*)(s_red + 4);
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const typename TT::elem* src = map + (size_t)b * HW * C;
+  // pooling: the C/8 8-channel groups x `nparts` interleaved row subsets over the 256 threads, partial sums meet in LDS
+  const int C8 = C >> 3, nparts = C8 < 256 ? 256 / C8 : 1;
+  float* s_part = s_e + C + 8;  // [nparts][C]
+  auto pool_group = [&](int c8, int part) {
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = part; s < HW; s += nparts) {
+      float f[8];
+      unpack8<TT>(*(const u32x4_t*)(src + (size_t)s * C + c8 * 8), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += f[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s_part[part * C + c8 * 8 + j] = a[j];
+  };
+  if (C8 < 256) {
+    if (tid < C8 * nparts) pool_group(tid % C8, tid / C8);
+  } else {
+    for (int c8 = tid; c8 < C8; c8 += 256) pool_group(c8, 0);
+  }
+  __syncthreads();
+  float ss = 0.f;
+  {
+    const float inv = 1.0f / (float)HW;
+    for (int k = tid; k < C; k += 256) {
+      float v = 0.f;
+      for (int q = 0; q < nparts; ++q) v += s_part[q * C + k];
+      v *= inv;
+      s_e[k] = v;
+      ss += v * v;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  if (lane == 0) s_red[wave] = ss;
+  __syncthreads();
+  if (normalize) {
+    const float denom = fmaxf(sqrtf(s_red[0] + s_red[1] + s_red[2] + s_red[3]), eps);
+    for (int k = tid; k < C; k += 256) s_e[k] = s_e[k] / denom;
+    __syncthreads();
+  }
+  if (emb_out)
+    for (int k = tid; k < C; k += 256) emb_out[(size_t)b * C + k] = s_e[k];
+  // compare_faces scan (as match_small_kernel): wave w scores rows 8w..8w+7, 8(w+4)..; first strict minimum wins
+  float best = INFINITY;
+  int besti = 0x7FFFFFFF;
+  for (int g0 = wave * 8; g0 < G; g0 += 32) {
+    float s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s2[j] = 0.f;
+    for (int k = lane; k < C; k += 64) {
+      const float e = s_e[k];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int gi = min(g0 + j, G - 1);
+        const float d = (e - gal[(size_t)gi * C + k]) + 1e-6f;
+        s2[j] += d * d;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = s2[j];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (g0 + j < G && v < best) { best = v; besti = g0 + j; }
+    }
+  }
+  __syncthreads();  // (s_red is reused)
+  if (lane == 0) { s_red[wave] = best; s_idx[wave] = besti; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (s_red[w] < best || (s_red[w] == best && s_idx[w] < besti)) { best = s_red[w]; besti = s_idx[w]; }
+    const bool any = besti != 0x7FFFFFFF;
+    const float d = any ? sqrtf(best) : INFINITY;
+    const int bi = any ? besti : -1;
+    idx_out[b] = bi;
+    dist_out[b] = d;
+    const int idt = (any && d <= thresh) ? bi : -1;
+    if (id_thr_out) id_thr_out[b] = idt;
+    if (packed_out) { packed_out[2 * b] = idt; packed_out[2 * b + 1] = __float_as_int(d); }
+  }
+}
+
+extern "C" int frmap_gap_norm_match(const void* map, const float* gallery, float* emb_out, int32_t* idx_out, float* dist_out,
+                                    int32_t* id_or_unknown_out, int32_t* packed_out, float thresh, int normalize, float eps,
+                                    int B, int HW, int C, int G, int dtype, void* stream) {
+  FRMAP_REQUIRE(map && idx_out && dist_out, "gap_norm_match: null pointer");
+  FRMAP_REQUIRE(dtype == FRMAP_BF16 || dtype == FRMAP_F16, "gap_norm_match: bad dtype");
+  FRMAP_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 8 == 0 && C <= 4096, "gap_norm_match: bad shape B=%d HW=%d C=%d", B, HW, C);
+  FRMAP_REQUIRE(G >= 0 && G <= 64 && (G == 0 || gallery), "gap_norm_match: gallery of 0..64 rows expected (got %d)", G);
+  const int c8 = C / 8, nparts = c8 < 256 ? 256 / c8 : 1;
+  const size_t lds = (size_t)(C + 8 + nparts * C) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == FRMAP_BF16)
+    hipLaunchKernelGGL(gap_norm_match_kernel<BF16>, dim3(B), dim3(256), lds, st, (const __bf16*)map, gallery, emb_out, idx_out,
+                       dist_out, id_or_unknown_out, packed_out, thresh, normalize, eps, HW, C, G);
+  else
+    hipLaunchKernelGGL(gap_norm_match_kernel<F16>, dim3(B), dim3(256), lds, st, (const _Float16*)map, gallery, emb_out, idx_out,
+                       dist_out, id_or_unknown_out, packed_out, thresh, normalize, eps, HW, C, G);
+  FRMAP_LAUNCH_CHECK();
+  return 0;
+}
+
 __global__ void argkey_finalize_kernel(const unsigned long long* __restrict__ keys, int32_t* __restrict__ out, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < B) out[b] = keys[b] ? (int32_t)(0xFFFFFFFFu - (unsigned)(keys[b] & 0xFFFFFFFFull)) : -1;

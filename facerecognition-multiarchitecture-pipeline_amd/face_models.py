@@ -297,6 +297,12 @@ class ResNetTransfer(_HipModule):
         fc = self.resnet.fc[1]
         return ops.linear_f32(f, fc.weight.detach(), None, fc.bias.detach())
 
+    def trunk_map(self, x):
+        """The NHWC trunk output whose global average pool is ``get_embedding`` (`face_models.py:98-102`); lets
+        ``matching.embed_and_match`` pool, normalise and match in one kernel."""
+        x = self._check_input(x)
+        return self._get_plan().features(x)
+
     def get_embedding(self, x):
         x = self._check_input(x)
         return self._get_plan().pooled(x).squeeze()  # `.squeeze()` as the reference (`:102`): (512,) at B == 1

@@ -120,6 +120,12 @@ def embed_and_match(model, x: torch.Tensor, gallery, thresh: float = REC_THRESH,
     ``normalize=True`` L2-normalises the embeddings first (for models whose embedding is not
     unit-norm: 'baseline', 'cnn', 'hybrid').  ``packed=True`` returns instead the int32 ``[B, 2]``
     record tensor ``(id, bits(dist))`` the multi-GPU all-gather ships (``dist.gather_packed``)."""
+    g = _as_gallery(gallery, x.device if isinstance(x, torch.Tensor) and x.is_cuda else "cuda")
+    fmap = model.trunk_map(x) if hasattr(model, "trunk_map") and len(g) <= 64 else None
+    if fmap is not None:
+        # embedding == global average pool of the trunk map (ResNetTransfer): pool + normalise + match in one launch
+        _idx, dist, ids, pk, _ = ops.gap_norm_match(fmap, g.matrix if len(g) else None, thresh, normalize=normalize, packed=packed)
+        return pk if packed else (ids, dist)
     emb = model.get_embedding(x)
     if emb.dim() == 1:
         emb = emb.unsqueeze(0)

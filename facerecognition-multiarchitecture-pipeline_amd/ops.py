@@ -390,6 +390,32 @@ def match_top1(emb: torch.Tensor, gallery: torch.Tensor, thresh: Optional[float]
     return (idx, dist) if thresh is None else (idx, dist, ids)
 
 
+def gap_norm_match(fmap: torch.Tensor, gallery: torch.Tensor, thresh: Optional[float] = None, normalize: bool = False,
+                   eps: float = 1e-12, want_emb: bool = False, packed: bool = False):
+    """Global-average-pool an NHWC trunk map [B,H,W,C], optionally L2-normalise, and match against a small gallery
+    (<= 64 rows) in one launch.  Returns (idx, dist, ids | None, packed | None, emb | None)."""
+    fmap = _dev(fmap, "gap_norm_match.map")
+    B, H, W, Cc = fmap.shape
+    G = int(gallery.shape[0]) if gallery is not None else 0
+    gptr = 0
+    if G > 0:
+        gallery = _dev(gallery, "gap_norm_match.gallery", torch.float32)
+        if gallery.shape[1] != Cc:
+            raise ValueError(f"gap_norm_match: map channels {Cc} != gallery dim {gallery.shape[1]}")
+        gptr = gallery.data_ptr()
+    idx = torch.empty((B,), dtype=torch.int32, device=fmap.device)
+    dist = torch.empty((B,), dtype=torch.float32, device=fmap.device)
+    ids = torch.empty((B,), dtype=torch.int32, device=fmap.device) if thresh is not None else None
+    pk = torch.empty((B, 2), dtype=torch.int32, device=fmap.device) if packed else None
+    emb = torch.empty((B, Cc), dtype=torch.float32, device=fmap.device) if want_emb else None
+    _lib.check(_lib.load().frmap_gap_norm_match(fmap.data_ptr(), gptr, emb.data_ptr() if emb is not None else 0, idx.data_ptr(),
+                                                dist.data_ptr(), ids.data_ptr() if ids is not None else 0,
+                                                pk.data_ptr() if pk is not None else 0,
+                                                float(thresh) if thresh is not None else float("inf"), int(bool(normalize)),
+                                                float(eps), B, H * W, Cc, G, dt_code(fmap.dtype), _stream()), "gap_norm_match")
+    return idx, dist, ids, pk, emb
+
+
 def cosine_logits(x: torch.Tensor, w: torch.Tensor, s: float = 1.0, want_logits: bool = True,
                   want_argmax: bool = True):
     x = _dev(x, "cosine_logits.x", torch.float32)

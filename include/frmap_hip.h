@@ -225,6 +225,15 @@ size_t frmap_head_workspace_bytes(int B, int C);
 int frmap_match_top1(const float* emb, const float* gallery, int32_t* idx_out, float* dist_out,
                      int32_t* id_or_unknown_out, int32_t* packed_out, float thresh, void* workspace,
                      int B, int G, int D, void* stream);
+
+/* The tail of the ResNet-18 ('cnn') embed-and-match step for small galleries in ONE launch, one workgroup per face:
+ * AdaptiveAvgPool2d(1) of the trunk map (face_models.py:100) -> optional F.normalize(eps) -> compare_faces' scan
+ * (src/app.py:58-64) exactly as frmap_match_top1 does it for G <= 64.
+ *   map : [B][HW][C] (dtype) trunk output (NHWC);  gallery : fp32 [G][C], 0 <= G <= 64
+ *   emb_out : fp32 [B][C] pooled (and normalised, if asked) embedding, or NULL;  other outputs as frmap_match_top1. */
+int frmap_gap_norm_match(const void* map, const float* gallery, float* emb_out, int32_t* idx_out, float* dist_out,
+                         int32_t* id_or_unknown_out, int32_t* packed_out, float thresh, int normalize, float eps,
+                         int B, int HW, int C, int G, int dtype, void* stream);
 int frmap_cosine_logits(const float* x, const float* w, float* logits_out, int32_t* argmax_out,
                         void* workspace, int B, int C, int D, float s, void* stream);
 int frmap_arcmargin_eval(const float* x, const float* w, const int64_t* label, float* logits_out,

@@ -144,6 +144,27 @@ def test_ensemble_on_gpu(gold_dir, calibrated_sd):
         assert torch.equal(single(x.to(DEV)), members[0](x.to(DEV)))   # one valid member: returned as is (:902-904)
 
 
+def test_fused_pool_norm_match_equals_unfused(calibrated_sd):
+    """embed_and_match's one-launch tail for ResNetTransfer (pool + normalise + match) against the three-kernel path."""
+    from frmap_amd import ops
+    sd = calibrated_sd("cnn")
+    m = _model("cnn", sd, torch.float16)
+    x = weights.golden_inputs("cnn").to(DEV)
+    gal = synth.unit_rows(3002, 36, 512).to(DEV)
+    with torch.no_grad():
+        emb = ops.l2_normalize(m.get_embedding(x), 1e-12)
+        idx_u, dist_u, ids_u = ops.match_top1(emb, gal, 1.3)
+        ids_f, dist_f = matching.embed_and_match(m, x, matching.Gallery([f"id{i}" for i in range(36)], gal, DEV), 1.3, normalize=True)
+        idx2, dist2, ids2, pk, emb2 = ops.gap_norm_match(m.trunk_map(x), gal, 1.3, normalize=True, want_emb=True, packed=True)
+    assert torch.equal(ids_f.cpu(), ids_u.cpu()) and torch.equal(idx2.cpu(), idx_u.cpu())
+    assert torch.allclose(dist_f.cpu(), dist_u.cpu(), atol=1e-5) and torch.allclose(emb2.cpu(), emb.cpu(), atol=1e-6)
+    assert torch.equal(pk[:, 0].cpu(), ids2.cpu()) and torch.equal(pk.view(torch.float32)[:, 1].cpu(), dist2.cpu())
+    # raw (unnormalised) pooled embedding, empty gallery -> the "Unknown"/inf sentinel of compare_faces
+    i0, d0, s0, _, e0 = ops.gap_norm_match(m.trunk_map(x), None, 1.0, normalize=False, want_emb=True)
+    assert torch.allclose(e0.cpu(), m.get_embedding(x).cpu(), atol=1e-6)
+    assert bool((i0 == -1).all()) and bool(torch.isinf(d0).all()) and bool((s0 == -1).all())
+
+
 def test_arcface_top1_identical_fp16(calibrated_sd):
     """Enrolment-style gallery (SURVEY.md §7 hard part 3): gallery = oracle embeddings of 36 faces,
     probes = the same faces perturbed; HIP top-1 and distance must equal the CPU reference's."""
