@@ -119,21 +119,22 @@ def embed_and_match(model, x: torch.Tensor, gallery, thresh: float = REC_THRESH,
     ``ids[b] = -1`` where the best distance exceeds ``thresh`` (compare_faces' "Unknown").
     ``normalize=True`` L2-normalises the embeddings first (for models whose embedding is not
     unit-norm: 'baseline', 'cnn', 'hybrid').  ``packed=True`` returns instead the int32 ``[B, 2]``
-    record tensor ``(id, bits(dist))`` the multi-GPU all-gather ships (``dist.gather_packed``)."""
+    record tensor ``(id, bits(dist))`` the multi-GPU all-gather ships (``dist.gather_packed``); ``packed=<tensor>``
+    writes those records into the given int32 ``[B, 2]`` buffer (a slice of a larger step buffer)."""
     g = _as_gallery(gallery, x.device if isinstance(x, torch.Tensor) and x.is_cuda else "cuda")
     fmap = model.trunk_map(x) if hasattr(model, "trunk_map") and len(g) <= 64 else None
     if fmap is not None:
         # embedding == global average pool of the trunk map (ResNetTransfer): pool + normalise + match in one launch
         _idx, dist, ids, pk, _ = ops.gap_norm_match(fmap, g.matrix if len(g) else None, thresh, normalize=normalize, packed=packed)
-        return pk if packed else (ids, dist)
+        return pk if (packed is not None and packed is not False) else (ids, dist)
     emb = model.get_embedding(x)
     if emb.dim() == 1:
         emb = emb.unsqueeze(0)
     if normalize:
         emb = ops.l2_normalize(emb, 1e-12)
     g = _as_gallery(gallery, emb.device)
-    if packed:
-        return ops.match_top1(emb.to(torch.float32), g.matrix, thresh, packed=True)[3]
+    if packed is not None and packed is not False:
+        return ops.match_top1(emb.to(torch.float32), g.matrix, thresh, packed=packed)[3]
     _idx, dist, ids = ops.match_top1(emb.to(torch.float32), g.matrix, thresh)
     return ids, dist
 
@@ -173,22 +174,27 @@ class GraphedEmbedMatch:
         with torch.cuda.graph(self.graph), torch.no_grad():
             self.records = self._run()
 
-    def _one(self, xs):
-        return embed_and_match(self.model, xs, self.gallery, self.thresh, normalize=self.normalize, packed=True)
+    def _one(self, xs, out):
+        return embed_and_match(self.model, xs, self.gallery, self.thresh, normalize=self.normalize, packed=out)
 
     def _run(self):
+        # every micro-batch writes its records straight into its slice of one buffer (no concatenation kernel at the join)
+        rec = torch.empty((self.x.shape[0], 2), dtype=torch.int32, device=self.x.device)
         if self.streams == 1:
-            return self._one(self.x)
+            return self._one(self.x, rec)
         main = torch.cuda.current_stream()
-        outs = [None] * self.streams
+        lo, slices = 0, []
+        for xs in self._xs:
+            slices.append(rec[lo: lo + xs.shape[0]])
+            lo += xs.shape[0]
         for i, st in enumerate(self._side):
             st.wait_stream(main)
             with torch.cuda.stream(st):
-                outs[i + 1] = self._one(self._xs[i + 1])
-        outs[0] = self._one(self._xs[0])
+                self._one(self._xs[i + 1], slices[i + 1])
+        self._one(self._xs[0], slices[0])
         for st in self._side:
             main.wait_stream(st)
-        return torch.cat(outs, dim=0)
+        return rec
 
     def __call__(self, x: Optional[torch.Tensor] = None) -> torch.Tensor:
         if x is not None and x.data_ptr() != self.x.data_ptr():

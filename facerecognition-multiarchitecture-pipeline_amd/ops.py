@@ -362,6 +362,19 @@ def _workspace(B: int, Cc: int, device) -> torch.Tensor:
     return torch.empty(((n + 15) // 16) * 2, dtype=torch.int64, device=device)
 
 
+def _packed_buf(packed, B: int, device):
+    """``packed``: False/None -> no record output; True -> a fresh int32 [B, 2]; a tensor -> written in place (a
+    contiguous int32 [B, 2] view, e.g. one micro-batch's slice of the step's record buffer)."""
+    if packed is None or packed is False:
+        return None
+    if packed is True:
+        return torch.empty((B, 2), dtype=torch.int32, device=device)
+    if not (isinstance(packed, torch.Tensor) and packed.is_cuda and packed.dtype == torch.int32 and tuple(packed.shape) == (B, 2)
+            and packed.is_contiguous()):
+        raise ValueError(f"packed output must be a contiguous int32 [{B}, 2] device tensor")
+    return packed
+
+
 def match_top1(emb: torch.Tensor, gallery: torch.Tensor, thresh: Optional[float] = None, packed: bool = False):
     """First arg-min over gallery rows of ``||e - g + 1e-6||_2`` and that distance (int32[B], fp32[B]).
     With ``thresh`` a third tensor is returned: idx where dist <= thresh else -1 ("Unknown");
@@ -379,13 +392,13 @@ def match_top1(emb: torch.Tensor, gallery: torch.Tensor, thresh: Optional[float]
     dist = torch.empty((B,), dtype=torch.float32, device=emb.device)
     ws = _workspace(B, G, emb.device)
     ids = torch.empty((B,), dtype=torch.int32, device=emb.device) if thresh is not None else None
-    pk = torch.empty((B, 2), dtype=torch.int32, device=emb.device) if packed else None
+    pk = _packed_buf(packed, B, emb.device)
     _lib.check(_lib.load().frmap_match_top1(emb.data_ptr(), gptr, idx.data_ptr(), dist.data_ptr(),
                                             ids.data_ptr() if ids is not None else 0,
                                             pk.data_ptr() if pk is not None else 0,
                                             float(thresh) if thresh is not None else float("inf"), ws.data_ptr(),
                                             B, G, D, _stream()), "match_top1")
-    if packed:
+    if pk is not None:
         return idx, dist, ids, pk
     return (idx, dist) if thresh is None else (idx, dist, ids)
 
@@ -406,7 +419,7 @@ def gap_norm_match(fmap: torch.Tensor, gallery: torch.Tensor, thresh: Optional[f
     idx = torch.empty((B,), dtype=torch.int32, device=fmap.device)
     dist = torch.empty((B,), dtype=torch.float32, device=fmap.device)
     ids = torch.empty((B,), dtype=torch.int32, device=fmap.device) if thresh is not None else None
-    pk = torch.empty((B, 2), dtype=torch.int32, device=fmap.device) if packed else None
+    pk = _packed_buf(packed, B, fmap.device)
     emb = torch.empty((B, Cc), dtype=torch.float32, device=fmap.device) if want_emb else None
     _lib.check(_lib.load().frmap_gap_norm_match(fmap.data_ptr(), gptr, emb.data_ptr() if emb is not None else 0, idx.data_ptr(),
                                                 dist.data_ptr(), ids.data_ptr() if ids is not None else 0,
