@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--settle-steps", type=int, default=150, dest="settle_steps",
+                    help="untimed steady-state settling steps before the warm-up steps (clock / power-state ramp)")
     ap.add_argument("--batch", type=int, default=256, help="faces per GPU per step")
     ap.add_argument("--gallery", type=int, default=36)
     ap.add_argument("--model", default="cnn", choices=["cnn", "arcface", "baseline", "siamese", "hybrid", "attention"])
@@ -133,14 +135,45 @@ def main():
             main.wait_stream(st)
         return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
 
+    # N > 1: the all-gather of step i (8 B/face, pure latency) runs on its own stream under step i+1's kernels;
+    # the records are first copied out of the step's buffer (the next graph replay overwrites it)
+    overlap = world > 1 and backend == "nccl" and os.environ.get("FRMAP_BENCH_OVERLAP_GATHER", "1") == "1"
+    if overlap:
+        comm = torch.cuda.Stream(device=dev)
+        staging = [torch.empty((B, 2), dtype=torch.int32, device=dev) for _ in range(2)]
+        gathered = [torch.empty((world * B, 2), dtype=torch.int32, device=dev) for _ in range(2)]
+        ready_ev = [torch.cuda.Event() for _ in range(2)]
+        copied_ev = [torch.cuda.Event() for _ in range(2)]
+    state = {"n": 0}
+
     def step():
         if world == 1:
             return local_step()
         # the match kernel emits the 8-byte (id, distance) records; one all-gather collates them
+        if not overlap:
+            rec = graphed() if graphed is not None else frmap_amd.embed_and_match(model, x, gallery, 1.0, normalize=need_norm, packed=True)
+            return fdist.gather_packed(rec)
+        k = state["n"] & 1
+        main = torch.cuda.current_stream()
+        if state["n"] > 0:
+            main.wait_event(copied_ev[k ^ 1])  # the previous step's records have left the buffer this step overwrites
         rec = graphed() if graphed is not None else frmap_amd.embed_and_match(model, x, gallery, 1.0, normalize=need_norm, packed=True)
-        return fdist.gather_packed(rec)
+        ready_ev[k].record(main)
+        with torch.cuda.stream(comm):
+            comm.wait_event(ready_ev[k])
+            staging[k].copy_(rec)
+            copied_ev[k].record(comm)
+            dist.all_gather_into_tensor(gathered[k], staging[k])
+        state["n"] += 1
+        return gathered[k][:, 0], gathered[k].view(torch.float32)[:, 1]
 
     with torch.no_grad():
+        # settle: the first ~50 steps after start-up run 5-12 % slower (clocks / power state ramping up: 218 k faces/s
+        # over steps 6-10, 248 k in steady state); run untimed settling steps before the W warm-up steps
+        # (a fixed COUNT, not a wall time: every rank must issue the same number of collectives)
+        for _ in range(max(args.settle_steps, 0)):
+            step()
+        torch.cuda.synchronize()
         for _ in range(max(args.warmup, 1) if args.warmup > 0 else 0):
             step()
         if world > 1:
@@ -238,7 +271,7 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"ResNet18 ('{args.model}') embed + L2-normalise + top-1 match, batch {B}/GPU, "
                                    f"{G}-ID gallery, 224x224x3 fp32 NCHW inputs resident in HBM, random-init weights",
-                       "global_batch": total, "parallelism": f"dp{world} (faces sharded, 1 all-gather of 8 B/face)",
+                       "global_batch": total, "parallelism": f"dp{world} (faces sharded, 1 all-gather of 8 B/face" + (", overlapped with the next step" if world > 1 else "") + ")",
                        "execution": (f"HIP graph replay, {args.streams} concurrent micro-batch streams" if graphed is not None
                                      else f"eager launches, {args.streams} stream(s)" + graph_note)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
