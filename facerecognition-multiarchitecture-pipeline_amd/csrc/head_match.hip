@@ -339,11 +339,32 @@ __global__ __launch_bounds__(256) void gap_norm_match_kernel(const typename TT::
   float* s_part = s_e + C + 8;  // [nparts][C]
   auto pool_group = [&](int c8, int part) {
     float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int s = part; s < HW; s += nparts) {
-      float f[8];
-      unpack8<TT>(*(const u32x4_t*)(src + (size_t)s * C + c8 * 8), f);
+    int s = part;
+    for (; s + 15 * nparts < HW; s += 16 * nparts) {  // sixteen independent 16-byte loads in flight
+      u32x4_t r[16];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] += f[j];
+      for (int q = 0; q < 16; ++q) r[q] = *(const u32x4_t*)(src + (size_t)(s + q * nparts) * C + c8 * 8);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        float f[8];
+        unpack8<TT>(r[q], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += f[j];
+      }
+    }
+    {  // the last (< 16) rows of this subset: loads first (rows past the end re-read the last one with weight 0)
+      u32x4_t r[16];
+      const int n = s < HW ? (HW - 1 - s) / nparts + 1 : 0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) r[q] = *(const u32x4_t*)(src + (size_t)min(s + q * nparts, HW - 1) * C + c8 * 8);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        float f[8];
+        unpack8<TT>(r[q], f);
+        const float wq = q < n ? 1.0f : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = fmaf(wq, f[j], a[j]);
+      }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) s_part[part * C + c8 * 8 + j] = a[j];
@@ -379,25 +400,26 @@ __global__ __launch_bounds__(256) void gap_norm_match_kernel(const typename TT::
   // compare_faces scan (as match_small_kernel): wave w scores rows 8w..8w+7, 8(w+4)..; first strict minimum wins
   float best = INFINITY;
   int besti = 0x7FFFFFFF;
-  for (int g0 = wave * 8; g0 < G; g0 += 32) {
-    float s2[8];
+  for (int g0 = 0; g0 < G; g0 += 64) {  // this pass: rows g0 + wave, g0 + wave + 4, ... (16 per wave: one pass for G <= 64)
+    float s2[16];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s2[j] = 0.f;
+    for (int j = 0; j < 16; ++j) s2[j] = 0.f;
     for (int k = lane; k < C; k += 64) {
       const float e = s_e[k];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int gi = min(g0 + j, G - 1);
+      for (int j = 0; j < 16; ++j) {
+        const int gi = min(g0 + 4 * j + wave, G - 1);
         const float d = (e - gal[(size_t)gi * C + k]) + 1e-6f;
         s2[j] += d * d;
       }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 16; ++j) {  // ascending row index within the wave: strict < keeps the first minimum
       float v = s2[j];
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (g0 + j < G && v < best) { best = v; besti = g0 + j; }
+      const int gi = g0 + 4 * j + wave;
+      if (gi < G && v < best) { best = v; besti = gi; }
     }
   }
   __syncthreads();  // (s_red is reused)
