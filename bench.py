@@ -167,6 +167,22 @@ def main():
         state["n"] += 1
         return gathered[k][:, 0], gathered[k].view(torch.float32)[:, 1]
 
+    if overlap:
+        # self-check on the live system: one overlapped step must return exactly what the plain gather returns
+        with torch.no_grad():
+            try:
+                ids_o, d_o = step()
+                torch.cuda.synchronize()
+                rec0 = graphed() if graphed is not None else frmap_amd.embed_and_match(model, x, gallery, 1.0, normalize=need_norm, packed=True)
+                ids_p, d_p = fdist.gather_packed(rec0)
+                torch.cuda.synchronize()
+                same = bool(torch.equal(ids_o, ids_p)) and bool(torch.equal(d_o, d_p))
+            except Exception:
+                same = False
+            flag = torch.tensor([1 if same else 0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                overlap = False  # (every rank takes the same decision)
     with torch.no_grad():
         # settle: the first ~50 steps after start-up run 5-12 % slower (clocks / power state ramping up: 218 k faces/s
         # over steps 6-10, 248 k in steady state); run untimed settling steps before the W warm-up steps
@@ -271,7 +287,7 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"ResNet18 ('{args.model}') embed + L2-normalise + top-1 match, batch {B}/GPU, "
                                    f"{G}-ID gallery, 224x224x3 fp32 NCHW inputs resident in HBM, random-init weights",
-                       "global_batch": total, "parallelism": f"dp{world} (faces sharded, 1 all-gather of 8 B/face" + (", overlapped with the next step" if world > 1 else "") + ")",
+                       "global_batch": total, "parallelism": f"dp{world} (faces sharded, 1 all-gather of 8 B/face" + (", overlapped with the next step" if overlap else "") + ")",
                        "execution": (f"HIP graph replay, {args.streams} concurrent micro-batch streams" if graphed is not None
                                      else f"eager launches, {args.streams} stream(s)" + graph_note)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
