@@ -499,15 +499,24 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_wave_kernel(const ConvPara
   const int nt = Lb % ntiles, co0 = nt << 6;
   const int tx = p.Wo >> 3, tpi = (p.Ho >> 3) * tx;  // 8x8 patches per row / per image
   const int total = p.N * tpi;
-  const int wstride = (gridDim.x / ntiles) * 8;
-  int T = (Lb / ntiles) * 8 + wave;
+  // Tile rounds: in the full rounds wave slot s = 8 * workgroup + wave takes tile r * W + s (neighbouring patches on
+  // one CU).  The last, partial round is dealt wave-major instead (wave 0 of every workgroup first): its `rem` extra
+  // tiles land on `rem` different CUs, one SIMD each, where they finish in about half a round once their SIMD
+  // partner is done - instead of 8 extra tiles on each of rem/8 CUs, a whole extra round there (256 faces: 6.5
+  // rounds instead of 7; 128 faces per stream: 3.5 instead of 4).
+  const int nwg = gridDim.x / ntiles, W = nwg * 8;
+  const int full = total / W, rem = total - full * W;
+  const int slot = (Lb / ntiles) * 8 + wave, spread = wave * nwg + Lb / ntiles;
+  auto tile_of = [&](int r) { return r < full ? r * W + slot : (r == full && spread < rem ? full * W + spread : -1); };
+  int rnd = 0;
+  int T = tile_of(0);
 
   {  // the resident weight slab of channel tile nt (both chunks, all taps), already in LDS-image order
     const char* wsrc = (const char*)p.wpk + (size_t)nt * wbytes;
     for (int o = tid * 16; o < wbytes; o += 512 * 16) *(u32x4_t*)(wl + o) = *(const u32x4_t*)(wsrc + o);
   }
   __syncthreads();
-  if (T >= total) return;
+  if (T < 0) return;
 
   const int woff = (lr << 6) + ((g ^ (((lr >> 2) & 1) << 1)) << 4);
   const elem* inp = (const elem*)p.in;
@@ -554,7 +563,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_wave_kernel(const ConvPara
   for (int u = 0; u < NH; ++u) hv[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)soff[u], 0, 0);
   int p_n = -1, p_by = 0, p_bx = 0;  // the tile whose packed outputs sit in ov[]
 
-  for (; T < total; T += wstride) {
+  for (; T >= 0; T = tile_of(++rnd)) {
     const int c_n = t_n, c_by = t_by, c_bx = t_bx;
     f32x4_t acc[MI][NI];
 #pragma unroll
@@ -581,8 +590,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_wave_kernel(const ConvPara
       } else {
         rs_io = io_rsrc(p.res ? p.res : p.out, c_n, c_by, c_bx, p.res != nullptr);
         pso = 0;
-        const bool more = T + wstride < total;
-        setup_load(more ? T + wstride : T, more);
+        const int Tn = tile_of(rnd + 1);
+        const bool more = Tn >= 0;
+        setup_load(more ? Tn : T, more);
       }
       auto memop = [&](int i) {
         if (i < NO) {
