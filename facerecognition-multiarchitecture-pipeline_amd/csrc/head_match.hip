@@ -12,6 +12,7 @@
 // 32-row halves.  fp32 in, fp32 accumulate: bitwise an fmaf chain, so arg-min / arg-max decisions
 // are taken on true fp32 scores.
 #include "frmap_common.h"
+#include <type_traits>
 
 enum { MODE_LINEAR = 0, MODE_COS = 1, MODE_ARC = 2, MODE_DIST = 3 };
 
@@ -43,12 +44,35 @@ __device__ __forceinline__ float f32_unordered(unsigned int k) {
   return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
 }
 
+// min (or max) of `v` over the 32 lanes of this lane's half-wave, and the LOWEST lane of the half holding it.
+// Four DPP steps inside each 16-lane row (quad xor 1, xor 2, half-mirror, mirror), one cross-row exchange,
+// then a ballot + find-first: ~10 instructions per reduced row where a 64-bit (value, index) butterfly took ~30.
+template <bool MAX>
+__device__ __forceinline__ float half_wave_best(float v, int lk, int& first_li) {
+  auto comb = [](float a, float b) { return MAX ? fmaxf(a, b) : fminf(a, b); };
+  auto dpp = [](float x, auto ctrl) {
+    const int i = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, decltype(ctrl)::value, 0xF, 0xF, false));
+  };
+  float m = v;
+  m = comb(m, dpp(m, std::integral_constant<int, 0xB1>{}));   // quad_perm [1,0,3,2]
+  m = comb(m, dpp(m, std::integral_constant<int, 0x4E>{}));   // quad_perm [2,3,0,1]
+  m = comb(m, dpp(m, std::integral_constant<int, 0x141>{}));  // row_half_mirror
+  m = comb(m, dpp(m, std::integral_constant<int, 0x140>{}));  // row_mirror
+  m = comb(m, __shfl_xor(m, 16, 64));
+  const unsigned long long hit = __ballot(v == m);
+  const unsigned half = lk ? (unsigned)(hit >> 32) : (unsigned)hit;
+  first_li = __ffs(half) - 1;  // >= 0: the lane(s) that contributed m are in the mask
+  return m;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restrict__ A, const float* __restrict__ W,
                                                           int B, int N, int K, GemmEpi ep) {
   constexpr int BMr = 64, BNc = 128, KC = 32, PITCH = KC + 1;
   __shared__ float As[BMr * PITCH];
   __shared__ float Ws[BNc * PITCH];
+  __shared__ unsigned long long s_key[4 * BMr];  // arg-min / arg-max keys per (wave, row) before the one atomic per row
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b0 = blockIdx.y * BMr, n0 = blockIdx.x * BNc;
   const int li = lane & 31, lk = lane >> 5;
@@ -130,14 +154,14 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
           if (ep.out) ep.out[(size_t)b * N + n] = v;
         }
         if (ep.argkey) {
-          // arg-max over n, first index wins ties: maximise (score, ~n)
-          unsigned long long key = valid ? (((unsigned long long)f32_ordered(v) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)n)) : 0ull;
-#pragma unroll
-          for (int o = 16; o > 0; o >>= 1) {
-            const unsigned long long other = __shfl_xor(key, o, 64);
-            key = other > key ? other : key;
+          // arg-max over n, first index wins ties: maximise (score, ~n); -inf marks columns / rows outside the problem
+          int fl;
+          const float best = half_wave_best<true>(v, lk, fl);
+          if (li == 0) {
+            const int nb = n0 + wave * 32 + fl;
+            s_key[wave * BMr + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk] =
+                (b < B && best > -INFINITY) ? (((unsigned long long)f32_ordered(best) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)nb)) : 0ull;
           }
-          if (li == 0 && b < B && key) atomicMax(ep.argkey + b, key);
         }
       } else if (MODE == MODE_ARC) {
         if (valid) {
@@ -157,20 +181,34 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
           ep.out[(size_t)b * N + n] = v;
         }
       } else {  // MODE_DIST: ||a - g + eps||^2 = |a|^2 + |g|^2 - 2 a.g + 2 eps (sum a - sum g) + K eps^2
-        unsigned long long key = ~0ull;
+        float d2 = INFINITY;  // columns / rows outside the problem never win
         if (valid) {
           const float eps = 1e-6f;
-          float d2 = ep.stat_a[2 * b] + wn2 - 2.f * dot + 2.f * eps * (ep.stat_a[2 * b + 1] - wsum) + (float)K * eps * eps;
+          d2 = ep.stat_a[2 * b] + wn2 - 2.f * dot + 2.f * eps * (ep.stat_a[2 * b + 1] - wsum) + (float)K * eps * eps;
           d2 = fmaxf(d2, 0.f);
-          key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)n;
         }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-          const unsigned long long other = __shfl_xor(key, o, 64);
-          key = other < key ? other : key;
+        int fl;
+        const float best = half_wave_best<false>(d2, lk, fl);
+        if (li == 0) {
+          const int nb = n0 + wave * 32 + fl;
+          s_key[wave * BMr + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk] =
+              (b < B && best < INFINITY) ? (((unsigned long long)__float_as_uint(best) << 32) | (unsigned)nb) : ~0ull;
         }
-        if (li == 0 && b < B && key != ~0ull) atomicMin(ep.argkey + b, key);
       }
+    }
+  }
+  if ((MODE == MODE_DIST || MODE == MODE_COS) && ep.argkey) {
+    // the four waves' candidates per row meet in LDS: one atomic per row and workgroup instead of one per row and wave
+    __syncthreads();
+    if (tid < BMr && b0 + tid < B) {
+      unsigned long long key = s_key[tid];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const unsigned long long o = s_key[w * BMr + tid];
+        key = MODE == MODE_DIST ? (o < key ? o : key) : (o > key ? o : key);
+      }
+      if (MODE == MODE_DIST) { if (key != ~0ull) atomicMin(ep.argkey + b0 + tid, key); }
+      else if (key) atomicMax(ep.argkey + b0 + tid, key);
     }
   }
   if (MODE == MODE_ARC && ep.minmax_key) {
