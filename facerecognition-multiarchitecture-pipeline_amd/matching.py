@@ -171,7 +171,8 @@ class GraphedEmbedMatch:
         torch.cuda.current_stream().wait_stream(warm)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
+        # thread_local: calls other threads make meanwhile (e.g. the NCCL watchdog polling events) must not invalidate the capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad():
             self.records = self._run()
 
     def _one(self, xs, out):
