@@ -1,142 +1,337 @@
 #!/usr/bin/env python3
 """Headline benchmark: faces/s for 224×224 embed + match (BASELINE.json), MI355X.
 
-A "step" = one pass of the hot path over one batch of synthetic faces already resident in HBM
-(default: the step is captured once into a HIP graph and replayed, the batch split into two
-micro-batches on concurrent streams — `frmap_amd.GraphedEmbedMatch`; `--graph 0 --streams 1` runs
-the same kernels as plain eager launches on one stream):
-fp32 NCHW batch → ResNet-18 embedding (HIP kernels, bf16 MFMA) → L2-normalise → top-1 match against
-a 36-ID gallery (configs[1]: "ResNet18 ('cnn') bf16 embed+match, batch 256, 1×MI355X, 36-ID
-gallery").  With N GPUs every rank runs the same per-GPU batch (weak scaling: faces shard
-embarrassingly) and one RCCL all-gather collates the (id, distance) pairs each step.
+A "step" = one pass of the hot path over one batch of synthetic faces already resident in HBM:
+fp32 NCHW batch → ResNet-18 embedding (HIP kernels, bf16 MFMA) → L2-normalise → top-1 match against the
+gallery.  Default execution: the step is captured once into a HIP graph and replayed, the batch split into
+two micro-batches on concurrent streams (`frmap_amd.GraphedEmbedMatch`); `--graph 0 --streams 1` runs the
+same kernels as plain eager launches on one stream (the mode the committed rocprofv3 profiles are taken in).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     — the dominant kernel (conv3x3_fast_kernel<BF16>: the 3×3 stride-1 implicit-GEMM
-                 convolutions, 13 launches per full-batch forward): algorithmic FLOPs per launch ÷ its
-                 average launch duration, measured with HIP events on the launch stream in a separate
-                 instrumented pass after the timed region — standalone eager launches at the full per-GPU
-                 batch on one stream (per-kernel durations are not defined for kernels that share the GPU
-                 with another stream's, and rocprofv3 serialises the streams); the committed rocprofv3
-                 summary is of `bench.py --graph 0 --streams 1`, the same launches.  peak = 2.5 PFLOP/s.
-  cpu_baseline — the CPU oracle (oracle/face_oracle.py, fp32 PyTorch restatement of the reference's
-                 forward) timed on this box's host cores on a bounded sample (rank 0, N=1 only).
+Workloads (BASELINE.json `configs`):
+  N = 1   configs[1]: ResNet18 ('cnn') bf16 embed+match, batch 256, 36-ID gallery  (the driver's BENCH line)
+  N > 1   configs[3]: ResNet18-ArcFace, 1024 faces per GPU (8192 on 8 GPUs), 10 000-ID gallery, one RCCL
+          all-gather of the 8-byte (id, distance) records per step (weak scaling: faces shard embarrassingly)
+  `--model/--batch/--gallery` override either.
+
+Launch: under `torch.distributed.run` (RANK / WORLD_SIZE in the environment) every rank runs `worker()`;
+`--gpus N` must then equal WORLD_SIZE.  Started plainly with `--gpus N > 1`, this process becomes a
+LAUNCHER: it never touches the GPU (no torch.cuda / HIP call), spawns N fresh rank processes with
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set, relays their output (rank 0 prints
+the JSON line) and exits non-zero if any rank does.  `FRMAP_BENCH_BACKEND=gloo` rehearses the N > 1 control
+flow on a box with fewer GPUs than ranks (ranks share devices; the collective runs over gloo on host copies).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with:
+  roofline      — the dominant kernel (conv3x3_fast_kernel<BF16, false>: the 3×3 stride-1 implicit-GEMM
+                  convolutions of layers 2-4): algorithmic FLOPs per launch ÷ its average launch duration,
+                  measured with HIP events on the launch stream in an instrumented pass after the timed region
+                  (standalone eager launches at the full per-GPU batch on one stream: per-kernel durations are not
+                  defined for kernels that share the GPU with another stream's, and rocprofv3 serialises the
+                  streams).  peak = 2.5 PFLOP/s dense bf16.  `layerwise` lists every kernel of the step with its
+                  algorithmic FLOPs / bytes, measured µs and roof time max(FLOP/peak, bytes/8 TB/s);
+                  `frac_layerwise` = Σ roof time ÷ measured.  `traffic` is the STORED rocprofv3 PMC measurement
+                  (profiles/*.json; PMC counters cannot be read from inside the process).
+  cpu_baseline  — the CPU oracle (oracle/face_oracle.py, fp32 PyTorch restatement of the reference's forward)
+                  timed on this box's host cores on a bounded sample (rank 0, N = 1 only).
+  fp16_value    — the same step in fp16 (the precision the north-star's 1e-3 / identical-top-1 tolerance is stated
+                  for), timed after the bf16 region in the same process (N = 1 only).
+  settle_steps  — untimed steps run BEFORE the W warm-up steps (clock / power-state ramp of a fresh process).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/fp16, MI355X_MICROARCH.md
-DOMINANT = "conv3x3_fast_kernel<BF16, false>"
+MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/fp16, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0       # HBM3E spec, MI355X_MICROARCH.md (≈6.3 TB/s achievable)
+TRAFFIC_PROFILE = "r02_hbm_traffic_pmc.json"
 
 
-def _pmc_traffic(kernel, args, dtype):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_hbm_traffic_pmc.json: separate FETCH_SIZE / WRITE_SIZE runs of this same command,
-    FETCH_SIZE doubled per the gfx950 correction).  PMC counters cannot be read from inside the
-    process, so this is the stored measurement; None when the configuration differs from the profiled one."""
-    if args.model != "cnn" or args.batch != 256 or dtype != torch.bfloat16:
-        return None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")) as f:
-            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
-    except Exception:
-        return None
-
-
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--settle-steps", type=int, default=150, dest="settle_steps",
-                    help="untimed steady-state settling steps before the warm-up steps (clock / power-state ramp)")
-    ap.add_argument("--batch", type=int, default=256, help="faces per GPU per step")
-    ap.add_argument("--gallery", type=int, default=36)
-    ap.add_argument("--model", default="cnn", choices=["cnn", "arcface", "baseline", "siamese", "hybrid", "attention"])
+                    help="untimed steady-state settling steps before the warm-up steps (clock / power-state ramp); "
+                         "reported as `settle_steps` in the JSON")
+    ap.add_argument("--batch", type=int, default=None, help="faces per GPU per step (default 256 at N=1, 1024 at N>1)")
+    ap.add_argument("--gallery", type=int, default=None, help="gallery identities (default 36 at N=1, 10000 at N>1)")
+    ap.add_argument("--model", default=None, choices=["cnn", "arcface", "baseline", "siamese", "hybrid", "attention"],
+                    help="default: cnn at N=1 (configs[1]), arcface at N>1 (configs[3])")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--input", default="f32", choices=["f32", "u8"],
+                    help="f32: fp32 NCHW crops (the reference's tensor layout, headline); u8: uint8 HWC crops normalised inside the stem")
     ap.add_argument("--streams", type=int, default=2, help="split the per-GPU batch over this many concurrent HIP streams")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step from a captured HIP graph (0: eager launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp16 / uint8-input side measurements")
+    return ap.parse_args(argv)
 
 
-def main():
-    args = parse()
+# ------------------------------------------------------------------------------------------------
+# launcher (parent of the rank processes): must not touch the GPU
+# ------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n: int, argv, worker_cmd=None, timeout: float = None) -> int:
+    """Spawn ``n`` rank processes of ``worker_cmd + argv`` (default: this script) with the torch.distributed
+    environment (RANK, LOCAL_RANK, WORLD_SIZE, LOCAL_WORLD_SIZE, MASTER_ADDR=127.0.0.1, MASTER_PORT) and wait.
+    stdout/stderr are inherited (rank 0 prints the JSON line).  Returns 0 iff every rank exited 0; on the first
+    failure the remaining ranks (exactly the PIDs started here) are terminated."""
+    cmd = list(worker_cmd) if worker_cmd else [sys.executable, os.path.abspath(__file__)]
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FRMAP_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(cmd + list(argv), env=env))
+    t0 = time.time()
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench launcher: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
+        if rc != 0 or (timeout is not None and time.time() - t0 > timeout):
+            if rc == 0:
+                rc = 124
+            for r in live:
+                procs[r].terminate()
+            for r in live:
+                try:
+                    procs[r].wait(15)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            break
+        if live:
+            time.sleep(0.05)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------
+# per-kernel instrumentation for the roofline objects
+# ------------------------------------------------------------------------------------------------
+def _nbytes(t):
+    return 0 if t is None else t.numel() * t.element_size()
+
+
+def _conv_kernel_name(dt, Cin, k, stride, H, W, ds):
+    if ds:
+        return f"conv3x3_fast_kernel<{dt}, true>"
+    if k == 1:
+        return f"conv1x1_kernel<{dt}>"
+    if stride == 2:
+        return f"conv3x3s2_fast_kernel<{dt}>"
+    if Cin == 64 and H % 8 == 0 and W % 8 == 0:
+        return f"conv3x3_c64_wave_kernel<{dt}>"
+    return f"conv3x3_fast_kernel<{dt}, false>"
+
+
+def instrument(ops, torch, dt):
+    """Wrap the op wrappers the embed+match step calls with HIP-event timers; returns (records, restore).
+    A record = dict(kernel, flop, bytes, e0, e1): algorithmic FLOPs (2·MAC of the contraction) and algorithmic
+    bytes (operands read once + output written once) of that launch."""
+    records, saved = [], {}
+
+    def wrap(name, describe):
+        orig = getattr(ops, name)
+        saved[name] = orig
+
+        def timed(*a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig(*a, **kw)
+            e1.record()
+            kern, flop, nbytes = describe(out, *a, **kw)
+            records.append(dict(kernel=kern, flop=float(flop), bytes=float(nbytes), e0=e0, e1=e1))
+            return out
+        setattr(ops, name, timed)
+
+    def d_conv(out, x, wpk, shift, Cout, k, stride, pad, relu, residual=None):
+        B, H, W, Cin = x.shape
+        flop = 2.0 * out.shape[0] * out.shape[1] * out.shape[2] * Cout * Cin * k * k
+        return _conv_kernel_name(dt, Cin, k, stride, H, W, False), flop, _nbytes(x) + _nbytes(out) + _nbytes(wpk) + _nbytes(residual)
+
+    def d_conv_ds(out, x, wpk, shift, Cout, x_ds, wpk_ds, ds_stride, relu):
+        B, H, W, Cin = x.shape
+        M = out.shape[0] * out.shape[1] * out.shape[2]
+        flop = 2.0 * M * Cout * (Cin * 9 + x_ds.shape[3])
+        gathered = M * x_ds.shape[3] * x_ds.element_size()      # only the strided pixels are needed
+        return _conv_kernel_name(dt, Cin, 3, 1, H, W, True), flop, _nbytes(x) + _nbytes(out) + _nbytes(wpk) + _nbytes(wpk_ds) + gathered
+
+    def d_stem(out, x, wpk, shift, dtype, pool3=True):
+        B, _, H, W = x.shape
+        Hc, Wc = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        return f"stem_pool_kernel<{dt}>", 2.0 * B * Hc * Wc * 64 * 147, _nbytes(x) + _nbytes(out) + _nbytes(wpk)
+
+    def d_stem_u8(out, x, wpk, shift, mean, std, dtype, pool3=True):
+        B, H, W, _ = x.shape
+        Hc, Wc = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        return f"stem_pool_u8_kernel<{dt}>", 2.0 * B * Hc * Wc * 64 * 147, _nbytes(x) + _nbytes(out) + _nbytes(wpk)
+
+    def d_gnm(out, fmap, gallery, *a, **kw):
+        B, H, W, C = fmap.shape
+        G = 0 if gallery is None else gallery.shape[0]
+        return f"gap_norm_match_kernel<{dt}>", 2.0 * B * C * G, _nbytes(fmap) + _nbytes(gallery) + 16 * B
+
+    def d_pool(out, x):
+        return "avgpool_global_kernel", 0.0, _nbytes(x) + _nbytes(out)
+
+    def d_lin(out, x, w, scale=None, shift=None, relu=False):
+        return "linear_f32 (gemm_nt_f32_kernel)", 2.0 * x.shape[0] * x.shape[1] * w.shape[0], _nbytes(x) + _nbytes(w) + _nbytes(out)
+
+    def d_l2(out, x, eps=1e-12):
+        return "l2_normalize_kernel", 0.0, 2 * _nbytes(x)
+
+    def d_match(out, emb, gallery, thresh=None, packed=False):
+        G = 0 if gallery is None else gallery.shape[0]
+        return "match_top1 (gemm_nt_f32_kernel + finalize)", 2.0 * emb.shape[0] * emb.shape[1] * G, _nbytes(emb) + _nbytes(gallery) + 16 * emb.shape[0]
+
+    for name, fn in (("conv_igemm", d_conv), ("conv_igemm_ds", d_conv_ds), ("stem7x7_maxpool", d_stem),
+                     ("stem7x7_maxpool_u8", d_stem_u8), ("gap_norm_match", d_gnm), ("avgpool_global", d_pool),
+                     ("linear_f32", d_lin), ("l2_normalize", d_l2), ("match_top1", d_match)):
+        if hasattr(ops, name):
+            wrap(name, fn)
+
+    def restore():
+        for k, v in saved.items():
+            setattr(ops, k, v)
+    return records, restore
+
+
+def stored_traffic():
+    """HBM bytes per launch per kernel from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE runs
+    of `bench.py --graph 0 --streams 1`, FETCH_SIZE doubled per the gfx950 correction)."""
+    for name in (TRAFFIC_PROFILE, "r01_hbm_traffic_pmc.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return name, {k: v["hbm_bytes_per_launch"] for k, v in json.load(f)["kernels"].items()}
+        except Exception:
+            continue
+    return None, {}
+
+
+# ------------------------------------------------------------------------------------------------
+# one rank
+# ------------------------------------------------------------------------------------------------
+def worker(args) -> int:
+    import torch
+    import torch.distributed as dist
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` "
+                         f"(spawns N ranks itself) or under torch.distributed.run with --nproc-per-node equal to --gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    # one rank per GPU; FRMAP_BENCH_BACKEND=gloo lets the N>1 control flow be rehearsed on a 1-GPU box
     backend = os.environ.get("FRMAP_BENCH_BACKEND", "nccl")
-    local_dev = local_rank % torch.cuda.device_count()
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        raise SystemExit(f"bench.py: {world} ranks but {ndev} visible GPU(s); RCCL needs one GPU per rank "
+                         "(FRMAP_BENCH_BACKEND=gloo rehearses the control flow with shared devices)")
+    local_dev = local_rank % ndev
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
+    rccl_ranks = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        world = dist.get_world_size()
+        if backend == "nccl":
+            # what RCCL itself saw: one int per rank through a real collective
+            probe = torch.ones(1, device=dev, dtype=torch.int32)
+            dist.all_reduce(probe)
+            rccl_ranks = int(probe.item())
 
     import frmap_amd
     from frmap_amd import dist as fdist
     from frmap_amd import ops, synth
 
+    cfg_multi = world > 1
+    model_type = args.model or ("arcface" if cfg_multi else "cnn")
+    B = args.batch or (1024 if cfg_multi else 256)
+    G = args.gallery or (10000 if cfg_multi else 36)
+    seeds = {"cnn": (1002, 2002, 3002), "arcface": (1004, 2004, 3004)}.get(model_type, (1002, 2002, 3002))
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
-    B, G = args.batch, args.gallery
-    model = frmap_amd.get_model(args.model, 36)
-    sd = synth.synth_state_dict(synth.shapes_of(model), 1002)
-    model.load_state_dict(sd)
-    model = model.to(dev).eval().set_compute_dtype(dtype)
-    gallery = frmap_amd.Gallery([f"id{i}" for i in range(G)], synth.unit_rows(3002, G, 512 if args.model != "siamese" else 256), dev)
+    D = 256 if model_type == "siamese" else 512
+
+    def build_model(dt):
+        m = frmap_amd.get_model(model_type, 36)
+        sd_ = synth.calibrated_state_dict(model_type, synth.shapes_of(m), seeds[0])   # = the parity tests' weights
+        m.load_state_dict(sd_)
+        return m.to(dev).eval().set_compute_dtype(dt), sd_
+
+    model, sd = build_model(dtype)
+    gallery = frmap_amd.Gallery([f"id{i}" for i in range(G)], synth.unit_rows(seeds[2], G, D), dev)
     gen = torch.Generator(device=dev)
-    gen.manual_seed(2002 + rank)
+    gen.manual_seed(seeds[1] + rank)
     x = torch.randn((B, 3, 224, 224), device=dev, dtype=torch.float32, generator=gen)  # resident in HBM
-    need_norm = args.model in ("cnn", "baseline", "hybrid", "attention")
+    need_norm = model_type in ("cnn", "baseline", "hybrid", "attention")
     total = B * world
 
-    graphed, graph_note = None, ""
-    if args.graph:
-        try:
-            graphed = frmap_amd.GraphedEmbedMatch(model, gallery, x, 1.0, normalize=need_norm, streams=args.streams)
-        except Exception as e:  # capture refused (e.g. another thread touched the device): same kernels, eager launches
-            graph_note = f" (graph capture failed: {type(e).__name__}; eager launches)"
-            torch.cuda.synchronize()
-    side = [torch.cuda.Stream(device=dev) for _ in range(max(args.streams - 1, 0))]
-    xs = list(x.chunk(args.streams)) if args.streams > 1 else [x]
+    def make_local_step(mdl, xin, use_graph, nstreams):
+        graphed, note = None, ""
+        if use_graph:
+            try:
+                graphed = frmap_amd.GraphedEmbedMatch(mdl, gallery, xin, 1.0, normalize=need_norm, streams=nstreams)
+            except Exception as e:  # capture refused: same kernels, eager launches
+                note = f" (graph capture failed: {type(e).__name__}; eager launches)"
+                torch.cuda.synchronize()
+        side = [torch.cuda.Stream(device=dev) for _ in range(max(nstreams - 1, 0))]
+        xs = list(xin.chunk(nstreams)) if nstreams > 1 else [xin]
+        rec = torch.empty((xin.shape[0], 2), dtype=torch.int32, device=dev)
 
-    def local_step():
-        if graphed is not None:
-            graphed()
-            return graphed.ids(), graphed.dists()
-        if args.streams == 1:
-            return frmap_amd.embed_and_match(model, x, gallery, 1.0, normalize=need_norm)
-        # micro-batches on concurrent streams: one stream's tail waves run beside the other's full waves
-        main = torch.cuda.current_stream()
-        outs = [None] * args.streams
-        for i, st in enumerate(side):
-            st.wait_stream(main)
-            with torch.cuda.stream(st):
-                outs[i + 1] = frmap_amd.embed_and_match(model, xs[i + 1], gallery, 1.0, normalize=need_norm)
-        outs[0] = frmap_amd.embed_and_match(model, xs[0], gallery, 1.0, normalize=need_norm)
-        for st in side:
-            main.wait_stream(st)
-        return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
+        def local_records():
+            """int32 [B, 2] (id-or-unknown, bits(dist)) records of this rank's faces."""
+            if graphed is not None:
+                return graphed()
+            if nstreams == 1:
+                return frmap_amd.embed_and_match(mdl, xin, gallery, 1.0, normalize=need_norm, packed=rec)
+            # micro-batches on concurrent streams, each writing its slice of the record buffer
+            main = torch.cuda.current_stream()
+            lo = xs[0].shape[0]
+            for st, xi in zip(side, xs[1:]):
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    frmap_amd.embed_and_match(mdl, xi, gallery, 1.0, normalize=need_norm, packed=rec[lo: lo + xi.shape[0]])
+                lo += xi.shape[0]
+            frmap_amd.embed_and_match(mdl, xs[0], gallery, 1.0, normalize=need_norm, packed=rec[: xs[0].shape[0]])
+            for st in side:
+                main.wait_stream(st)
+            return rec
+        return local_records, graphed is not None, note
+
+    local_records, is_graphed, graph_note = make_local_step(model, x, bool(args.graph), args.streams)
 
     # N > 1: the all-gather of step i (8 B/face, pure latency) runs on its own stream under step i+1's kernels;
-    # the records are first copied out of the step's buffer (the next graph replay overwrites it)
+    # the records are first copied out of the step's buffer (the next replay overwrites it)
     overlap = world > 1 and backend == "nccl" and os.environ.get("FRMAP_BENCH_OVERLAP_GATHER", "1") == "1"
     if overlap:
         comm = torch.cuda.Stream(device=dev)
@@ -148,20 +343,19 @@ def main():
 
     def step():
         if world == 1:
-            return local_step()
-        # the match kernel emits the 8-byte (id, distance) records; one all-gather collates them
+            r = local_records()
+            return r[:, 0], r.view(torch.float32)[:, 1]
         if not overlap:
-            rec = graphed() if graphed is not None else frmap_amd.embed_and_match(model, x, gallery, 1.0, normalize=need_norm, packed=True)
-            return fdist.gather_packed(rec)
+            return fdist.gather_packed(local_records())
         k = state["n"] & 1
         main = torch.cuda.current_stream()
         if state["n"] > 0:
             main.wait_event(copied_ev[k ^ 1])  # the previous step's records have left the buffer this step overwrites
-        rec = graphed() if graphed is not None else frmap_amd.embed_and_match(model, x, gallery, 1.0, normalize=need_norm, packed=True)
+        r = local_records()
         ready_ev[k].record(main)
         with torch.cuda.stream(comm):
             comm.wait_event(ready_ev[k])
-            staging[k].copy_(rec)
+            staging[k].copy_(r)
             copied_ev[k].record(comm)
             dist.all_gather_into_tensor(gathered[k], staging[k])
         state["n"] += 1
@@ -173,8 +367,7 @@ def main():
             try:
                 ids_o, d_o = step()
                 torch.cuda.synchronize()
-                rec0 = graphed() if graphed is not None else frmap_amd.embed_and_match(model, x, gallery, 1.0, normalize=need_norm, packed=True)
-                ids_p, d_p = fdist.gather_packed(rec0)
+                ids_p, d_p = fdist.gather_packed(local_records())
                 torch.cuda.synchronize()
                 same = bool(torch.equal(ids_o, ids_p)) and bool(torch.equal(d_o, d_p))
             except Exception:
@@ -183,69 +376,106 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 0:
                 overlap = False  # (every rank takes the same decision)
-    with torch.no_grad():
-        # settle: the first ~50 steps after start-up run 5-12 % slower (clocks / power state ramping up: 218 k faces/s
-        # over steps 6-10, 248 k in steady state); run untimed settling steps before the W warm-up steps
-        # (a fixed COUNT, not a wall time: every rank must issue the same number of collectives)
-        for _ in range(max(args.settle_steps, 0)):
-            step()
-        torch.cuda.synchronize()
-        for _ in range(max(args.warmup, 1) if args.warmup > 0 else 0):
-            step()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t1 = time.perf_counter()
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
-    faces_per_s = total * args.steps / elapsed
 
-    # ---------------- roofline of the dominant kernel (instrumented pass, not part of `value`) ----
+    def timed_region(step_fn, settle, warmup, steps, collective):
+        """settle + warmup untimed steps, then EXACTLY `steps` steps bracketed by barrier + synchronize on both sides."""
+        with torch.no_grad():
+            for _ in range(max(settle, 0)):      # a fixed COUNT: every rank must issue the same number of collectives
+                step_fn()
+            torch.cuda.synchronize()
+            for _ in range(max(warmup, 0)):
+                step_fn()
+            if collective:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step_fn()
+            torch.cuda.synchronize()
+            if collective:
+                dist.barrier()
+            return time.perf_counter() - t0
+
+    local_elapsed = timed_region(step, args.settle_steps, args.warmup, args.steps, world > 1)
+    elapsed_t = torch.tensor([local_elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(elapsed_t, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed_t.item())
+    faces_per_s = total * args.steps / elapsed
+    dt = "BF16" if dtype == torch.bfloat16 else "F16"
+
+    # ---------------- roofline: per-kernel instrumented pass (not part of `value`) ----------------
     roofline = None
     if rank == 0 and not args.no_roofline:
-        records = []
-        orig = ops.conv_igemm
-
-        def timed(x_, wpk, shift, Cout, k, stride, pad, relu, residual=None):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            y = orig(x_, wpk, shift, Cout, k, stride, pad, relu, residual)
-            e1.record()
-            Bn, H, W, Cin = x_.shape
-            records.append((e0, e1, k, stride, 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * Cout * Cin * k * k, Cin))
-            return y
-
         import frmap_amd.face_models as fm
-        fm.ops.conv_igemm = timed
+        import frmap_amd.matching as mt_
+        assert fm.ops is ops and mt_.ops is ops
+        records, restore = instrument(ops, torch, dt)
+        NREP = 5
         try:
             with torch.no_grad():
-                for _ in range(5):  # rank-local, eager, one stream, full batch
+                for _ in range(NREP):  # rank-local, eager, one stream, full per-GPU batch
                     frmap_amd.embed_and_match(model, x, gallery, 1.0, normalize=need_norm)
             torch.cuda.synchronize()
         finally:
-            fm.ops.conv_igemm = orig
-        # the dominant kernel = conv3x3_fast_kernel: the 3x3 stride-1 convs with Cin >= 128 (Cin = 64 runs conv3x3_c64_wave_kernel)
-        dom = [(e0.elapsed_time(e1) * 1e-3, fl) for e0, e1, k, s, fl, cin in records if k == 3 and s == 1 and cin >= 128]
-        allc = [(e0.elapsed_time(e1) * 1e-3, fl) for e0, e1, k, s, fl, cin in records]
+            restore()
+        prof_name, pmc = stored_traffic()
+        per = {}
+        for r in records:
+            a = per.setdefault(r["kernel"], dict(launches=0, flop=0.0, bytes=0.0, us=0.0))
+            a["launches"] += 1
+            a["flop"] += r["flop"]
+            a["bytes"] += r["bytes"]
+            a["us"] += r["e0"].elapsed_time(r["e1"]) * 1e3
+        layerwise, roof_total, meas_total = [], 0.0, 0.0
+        for kname, a in per.items():
+            n = a["launches"] // NREP
+            flop, nbytes, us = a["flop"] / NREP, a["bytes"] / NREP, a["us"] / NREP
+            roof_us = max(flop / (MFMA_PEAK_TFLOPS * 1e12), nbytes / (HBM_PEAK_GBS * 1e9)) * 1e6
+            roof_total += roof_us
+            meas_total += us
+            pm = pmc.get(kname)
+            layerwise.append({"kernel": kname, "launches_per_step": n, "flop": flop, "bytes": nbytes, "us": round(us, 2),
+                              "roof_us": round(roof_us, 2), "bound": "mfma" if flop / (MFMA_PEAK_TFLOPS * 1e12) >= nbytes / (HBM_PEAK_GBS * 1e9) else "hbm",
+                              "tflops": round(flop / us / 1e6, 1) if us > 0 else None, "gbs": round(nbytes / us / 1e3, 1) if us > 0 else None,
+                              "pmc_bytes": int(pm * n) if pm is not None else None})
+        dom_name = f"conv3x3_fast_kernel<{dt}, false>"
+        dom = per.get(dom_name)
         if dom:
-            tsum, fsum = sum(t for t, _ in dom), sum(f for _, f in dom)
-            achieved = fsum / tsum / 1e12
-            roofline = {"bound": "mfma", "kernel": DOMINANT if dtype == torch.bfloat16 else DOMINANT.replace("BF16", "F16"),
-                        "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": _pmc_traffic(DOMINANT, args, dtype),
-                        "measured": "standalone eager launches at the full per-GPU batch, one stream (instrumented pass)",
-                        "launches_per_step": len(dom) // 5, "avg_launch_us": round(tsum / len(dom) * 1e6, 2),
-                        "flop_per_launch": fsum / len(dom),
-                        "all_conv_igemm_tflops": round(sum(f for _, f in allc) / sum(t for t, _ in allc) / 1e12, 2),
-                        "conv_igemm_ms_per_step": round(sum(t for t, _ in allc) / 5 * 1e3, 3)}
+            achieved = dom["flop"] / dom["us"] / 1e6   # FLOP / µs / 1e6 = TFLOP/s
+            roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                        "traffic": pmc.get(dom_name), "traffic_source": {"stored": f"profiles/{prof_name}"} if prof_name else None,
+                        "measured": "standalone eager launches at the full per-GPU batch, one stream (instrumented pass, HIP events)",
+                        "launches_per_step": dom["launches"] // NREP, "avg_launch_us": round(dom["us"] / dom["launches"], 2),
+                        "flop_per_launch": dom["flop"] / dom["launches"],
+                        "layerwise": layerwise,
+                        "layerwise_roof_us": round(roof_total, 1), "layerwise_measured_us": round(meas_total, 1),
+                        "frac_layerwise": round(roof_total / meas_total, 4) if meas_total > 0 else None,
+                        "frac_layerwise_of_step": round(roof_total / (elapsed / args.steps * 1e6), 4),
+                        "peaks": {"mfma_tflops": MFMA_PEAK_TFLOPS, "hbm_gbs": HBM_PEAK_GBS}}
+
+    # ---------------- side measurements (N = 1, rank 0; outside the timed region) ----------------
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras and model_type in ("cnn", "arcface"):
+        try:
+            if args.dtype == "bf16":
+                m16, _ = build_model(torch.float16)
+                rec16, _, _ = make_local_step(m16, x, bool(args.graph), args.streams)
+                t16 = timed_region(rec16, 50, args.warmup, args.steps, False)
+                extras["fp16_value"] = round(B * args.steps / t16, 1)
+                del m16, rec16
+            if getattr(model, "supports_u8_input", False):
+                gen8 = torch.Generator(device=dev)
+                gen8.manual_seed(seeds[1] + 77)
+                x8 = torch.randint(0, 256, (B, 224, 224, 3), device=dev, dtype=torch.uint8, generator=gen8)
+                rec8, _, _ = make_local_step(model, x8, bool(args.graph), args.streams)
+                t8 = timed_region(rec8, 50, args.warmup, args.steps, False)
+                extras["u8_input_value"] = round(B * args.steps / t8, 1)
+                del rec8
+        except Exception as e:  # a side measurement must never cost the headline line
+            extras["extras_error"] = f"{type(e).__name__}: {e}"
+        torch.cuda.synchronize()
 
     # ---------------- CPU baseline: the oracle on the host cores (bounded sample) -----------------
     cpu_baseline = None
@@ -264,7 +494,7 @@ def main():
         gal = gallery.matrix.cpu()
         emb_fn = {"cnn": fo.cnn_embedding, "arcface": fo.arcface_embedding, "baseline": fo.baseline_embedding,
                   "siamese": fo.siamese_forward_one, "hybrid": fo.hybrid_embedding,
-                  "attention": fo.attention_embedding}[args.model]
+                  "attention": fo.attention_embedding}[model_type]
         best = float("inf")
         with torch.no_grad():
             for rep in range(4):
@@ -280,23 +510,37 @@ def main():
                                   f"{G}-ID match, best of 3 after 1 warm-up"}
 
     if rank == 0:
+        names = {"cnn": "ResNet18 ('cnn')", "arcface": "ResNet18-ArcFace ('arcface')"}
         line = {
             "metric": "faces/sec (224x224 embed+match)", "value": round(faces_per_s, 1), "unit": "faces/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": max(args.settle_steps, 0),
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"ResNet18 ('{args.model}') embed + L2-normalise + top-1 match, batch {B}/GPU, "
-                                   f"{G}-ID gallery, 224x224x3 fp32 NCHW inputs resident in HBM, random-init weights",
-                       "global_batch": total, "parallelism": f"dp{world} (faces sharded, 1 all-gather of 8 B/face" + (", overlapped with the next step" if overlap else "") + ")",
-                       "execution": (f"HIP graph replay, {args.streams} concurrent micro-batch streams" if graphed is not None
+            "config": {"workload": f"{names.get(model_type, model_type)} embed + L2-normalise + top-1 match, batch {B}/GPU, "
+                                   f"{G}-ID gallery, 224x224x3 fp32 NCHW inputs resident in HBM, seeded random-init weights "
+                                   f"with calibrated BatchNorm statistics (BASELINE.json configs[{3 if model_type == 'arcface' and G >= 10000 else 1}])",
+                       "global_batch": total,
+                       "parallelism": f"dp{world} (faces sharded, 1 all-gather of 8 B/face" + (", overlapped with the next step" if overlap else "") + ")",
+                       "backend": backend if world > 1 else None, "rccl_ranks": rccl_ranks,
+                       "execution": (f"HIP graph replay, {args.streams} concurrent micro-batch streams" if is_graphed
                                      else f"eager launches, {args.streams} stream(s)" + graph_note)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
+        line.update(extras)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None) -> int:
+    args = parse(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # launcher: spawn the ranks BEFORE anything in this process could touch the GPU (torch is not even imported)
+        return launch_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv))
+    return worker(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

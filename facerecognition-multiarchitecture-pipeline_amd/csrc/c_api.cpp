@@ -1,6 +1,11 @@
-// Error plumbing + version of the C ABI (include/frmap_hip.h).
+// Error plumbing, version of the C ABI (include/frmap_hip.h) and per-device kernel attributes.
+#include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+
+#include <mutex>
+#include <set>
+#include <utility>
 
 #include "../../include/frmap_hip.h"
 
@@ -13,5 +18,29 @@ void frmap_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int frmap_abi_version(void) { return 4; }
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: a process that launches on several
+// GPUs (the app-style use of SURVEY.md §8b: a model on any device, called from any thread) must raise it once per
+// (kernel, device), not once per process.  Returns 0, or -2 with the error text set.
+int frmap_big_lds(const void* kern, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) {
+    frmap_set_error("hipGetDevice: %s", hipGetErrorString(e));
+    return -2;
+  }
+  std::lock_guard<std::mutex> lock(mu);
+  const auto key = std::make_pair(kern, dev);
+  if (done.count(key)) return 0;
+  e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    frmap_set_error("hipFuncSetAttribute(device %d): %s", dev, hipGetErrorString(e));
+    return -2;
+  }
+  done.insert(key);
+  return 0;
+}
+
+extern "C" int frmap_abi_version(void) { return 5; }
 extern "C" const char* frmap_last_error(void) { return g_err; }

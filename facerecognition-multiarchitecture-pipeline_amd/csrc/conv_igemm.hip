@@ -1034,15 +1034,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const ConvParams p) {
 template <typename TT, int CKS>
 static int launch_1x1(const ConvParams& p, hipStream_t st) {
   auto kern = conv1x1_kernel<TT, CKS>;
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      frmap_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return -2;
-    }
-    attr = true;
-  }
+  if (frmap_big_lds((const void*)kern, 160 * 1024)) return -2;
   int lds = CKS * (256 * 64 + 4096);
   const int scratch = 4 * 16 * (4 * 64 + 16);
   if (lds < scratch) lds = scratch;
@@ -1082,15 +1074,7 @@ static int halo_rows_bound(int BM, int Ho, int Wo, int Hp, int stride, int KS) {
 template <typename TT, int BM, int KS, int SWZ>
 static int launch(const ConvParams& p, int lds_bytes, hipStream_t st) {
   auto kern = conv_igemm_kernel<TT, BM, KS, SWZ>;
-  static int attr_set = 0;
-  if (attr_set < lds_bytes) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      frmap_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return -2;
-    }
-    attr_set = 160 * 1024;
-  }
+  if (frmap_big_lds((const void*)kern, 160 * 1024)) return -2;
   const int scratch = 4 * 16 * (4 * 64 + 16);  // epilogue transpose region (4 waves)
   if (lds_bytes < scratch) lds_bytes = scratch;
   hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), lds_bytes, st, p);
@@ -1166,30 +1150,14 @@ static int conv_igemm_impl(const void* in, const void* w_packed, const float* sh
       p.halo_bytes = (int)hbs;
       p.nblocks = ((p.M + 255) / 256) * ntiles;
       const int lds = (int)hbs + 6 * 4096;
-      static bool attr[2] = {false, false};
       const void* kern = dtype == FRMAP_BF16 ? (const void*)conv3x3s2_split_kernel<BF16> : (const void*)conv3x3s2_split_kernel<F16>;
-      if (!attr[dtype]) {
-        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) {
-          frmap_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
-          return -2;
-        }
-        attr[dtype] = true;
-      }
+      if (frmap_big_lds(kern, 160 * 1024)) return -2;
       static int s2fast = -1;
       if (s2fast < 0) { const char* e = getenv("FRMAP_CONV_S2FAST"); s2fast = e ? atoi(e) : 1; }
       const bool fast2 = s2fast && hbs / 16 <= 12 * 256 && (long long)(256 / (Ho * Wo) + 3) * Hi * Wi * Cin * 2 < (1ll << 31);
       if (fast2) {
-        static bool attr2[2] = {false, false};
         const void* k2 = dtype == FRMAP_BF16 ? (const void*)conv3x3s2_fast_kernel<BF16> : (const void*)conv3x3s2_fast_kernel<F16>;
-        if (!attr2[dtype]) {
-          hipError_t e = hipFuncSetAttribute(k2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-          if (e != hipSuccess) {
-            frmap_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
-            return -2;
-          }
-          attr2[dtype] = true;
-        }
+        if (frmap_big_lds(k2, 160 * 1024)) return -2;
         if (dtype == FRMAP_BF16)
           hipLaunchKernelGGL(conv3x3s2_fast_kernel<BF16>, dim3(p.nblocks), dim3(256), lds, st, p);
         else
@@ -1235,15 +1203,7 @@ static int conv_igemm_impl(const void* in, const void* w_packed, const float* sh
       const int grid = per * ntiles;
       const int ldsw = 2 * wbytes + 8 * (10 * 16 * 64);
       const void* kern = dtype == FRMAP_BF16 ? (const void*)conv3x3_c64_wave_kernel<BF16> : (const void*)conv3x3_c64_wave_kernel<F16>;
-      static bool attr[2] = {false, false};
-      if (!attr[dtype]) {
-        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) {
-          frmap_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
-          return -2;
-        }
-        attr[dtype] = true;
-      }
+      if (frmap_big_lds(kern, 160 * 1024)) return -2;
       if (dtype == FRMAP_BF16)
         hipLaunchKernelGGL(conv3x3_c64_wave_kernel<BF16>, dim3(grid), dim3(512), ldsw, st, p);
       else
@@ -1259,15 +1219,7 @@ static int conv_igemm_impl(const void* in, const void* w_packed, const float* sh
     static const kern_t kerns[4] = {conv3x3_fast_kernel<BF16, false>, conv3x3_fast_kernel<BF16, true>,
                                     conv3x3_fast_kernel<F16, false>, conv3x3_fast_kernel<F16, true>};
     const int ki = (dtype == FRMAP_BF16 ? 0 : 2) + (ds.in ? 1 : 0);
-    static bool attr[4] = {false, false, false, false};
-    if (!attr[ki]) {
-      hipError_t e = hipFuncSetAttribute((const void*)kerns[ki], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) {
-        frmap_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
-        return -2;
-      }
-      attr[ki] = true;
-    }
+    if (frmap_big_lds((const void*)kerns[ki], 160 * 1024)) return -2;
     const int scratch = 4 * 16 * (4 * 64 + 16);
     const int ldsf = lds < scratch ? scratch : lds;
     hipLaunchKernelGGL(kerns[ki], dim3(grid), dim3(256), ldsf, st, p);

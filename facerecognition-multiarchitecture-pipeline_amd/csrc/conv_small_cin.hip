@@ -177,15 +177,7 @@ static int launch_small(SmallCinParams& p, hipStream_t st) {
   FRMAP_REQUIRE(hb + wbytes <= 160 * 1024, "conv_small_cin: rows too wide for LDS (W=%d)", p.Wi);
   p.halo_bytes = (int)hb;
   auto kern = conv_small_cin_kernel<TT, NI, KH, KW, STRIDE>;
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      frmap_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return -2;
-    }
-    attr = true;
-  }
+  if (frmap_big_lds((const void*)kern, 160 * 1024)) return -2;
   int lds = (int)hb + wbytes;
   const int scratch = 4 * 16 * (NI * 64 + 16);  // epilogue transpose region (4 waves)
   if (lds < scratch) lds = scratch;

@@ -198,6 +198,8 @@ __device__ __forceinline__ int frmap_div(int n, FrmapDiv d) { return d.m ? (int)
 
 // host-side error plumbing
 void frmap_set_error(const char* fmt, ...);
+// raise a kernel's dynamic-LDS limit on the CURRENT device (once per (kernel, device)); 0 or -2 with the error set
+int frmap_big_lds(const void* kern, int bytes);
 #define FRMAP_REQUIRE(cond, ...)        \
   do {                                  \
     if (!(cond)) {                      \

@@ -278,16 +278,8 @@ static int stem_launch(const float* x_nchw, const void* w_packed_c3, const float
       stem_pool_kernel<BF16, false, false>, stem_pool_kernel<BF16, false, true>, stem_pool_kernel<BF16, true, false>,
       stem_pool_kernel<BF16, true, true>,   stem_pool_kernel<F16, false, false>, stem_pool_kernel<F16, false, true>,
       stem_pool_kernel<F16, true, false>,   stem_pool_kernel<F16, true, true>};
-  static bool attr[8] = {false, false, false, false, false, false, false, false};
   const int ai = (dtype == FRMAP_BF16 ? 0 : 4) + (pool3 ? 2 : 0) + (vec4 ? 1 : 0);
-  if (!attr[ai]) {
-    hipError_t e = hipFuncSetAttribute((const void*)kerns[ai], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      frmap_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return -2;
-    }
-    attr[ai] = true;
-  }
+  if (frmap_big_lds((const void*)kerns[ai], 160 * 1024)) return -2;
   hipLaunchKernelGGL(kerns[ai], dim3(grid), dim3(256), lds, st, p);
   FRMAP_LAUNCH_CHECK();
   return 0;

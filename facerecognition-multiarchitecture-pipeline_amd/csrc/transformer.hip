@@ -205,16 +205,8 @@ extern "C" int frmap_mha_tokens(const void* qkv, void* out, int B, int L, int D,
   FRMAP_REQUIRE((long long)B * H < (1ll << 31), "mha_tokens: too many heads");
   const int lds = 2 * 64 * 272 + 128 * 144 + 4 * 16 * 144 + 4 * 16 * 272;
   hipStream_t st = (hipStream_t)stream;
-  static bool attr[2] = {false, false};
   const void* kern = dtype == FRMAP_BF16 ? (const void*)mha_tokens_kernel<BF16> : (const void*)mha_tokens_kernel<F16>;
-  if (!attr[dtype]) {
-    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    if (e != hipSuccess) {
-      frmap_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return -2;
-    }
-    attr[dtype] = true;
-  }
+  if (frmap_big_lds(kern, 96 * 1024)) return -2;
   if (dtype == FRMAP_BF16)
     hipLaunchKernelGGL(mha_tokens_kernel<BF16>, dim3(B * H), dim3(256), lds, st, (const __bf16*)qkv, (__bf16*)out, L, D, H);
   else
@@ -441,15 +433,7 @@ static int cnn_attention_launch(const CnnAttnParams& p, hipStream_t st) {
                      (size_t)p.L * p.C * sizeof(typename TT::elem);
   FRMAP_REQUIRE(lds <= 160 * 1024, "cnn_attention: %zu bytes of LDS needed (> 160 KB)", lds);
   auto kern = cnn_attention_kernel<TT, CPT, LMAX>;
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      frmap_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return -2;
-    }
-    attr = true;
-  }
+  if (frmap_big_lds((const void*)kern, 160 * 1024)) return -2;
   hipLaunchKernelGGL(kern, dim3(p.B), dim3(256), lds, st, p);
   FRMAP_LAUNCH_CHECK();
   return 0;

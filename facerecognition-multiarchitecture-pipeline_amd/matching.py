@@ -57,16 +57,33 @@ class Gallery:
 _gallery_cache: dict = {}
 
 
+def _refs_tag(refs) -> tuple:
+    """Content tag of a ``refs`` list: per entry the embedding object's identity, storage address and in-place
+    version counter — an in-place edit of an enrolled embedding, a replaced entry or a list that was freed and
+    reallocated at the same ``id`` all change it."""
+    tag = [len(refs)]
+    for r in refs:
+        e = r.get("embedding") if isinstance(r, dict) else None
+        if isinstance(e, torch.Tensor):
+            tag.append((id(e), e.data_ptr(), e._version, tuple(e.shape), r.get("name")))
+        else:
+            tag.append((id(e), r.get("name") if isinstance(r, dict) else None))
+    return tuple(tag)
+
+
 def _as_gallery(refs, device) -> Gallery:
     if isinstance(refs, Gallery):
         return refs
-    # the demo passes the same list object every frame (`app.py:639`); cache on identity + content tag
+    # the demo passes the same list object every frame (`app.py:639`): keep its device matrix while the list is unchanged
     key = id(refs)
-    tag = (len(refs), tuple(id(r.get("embedding")) for r in refs))
+    tag = _refs_tag(refs)
+    dev = torch.device(device)
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
     hit = _gallery_cache.get(key)
-    if hit is not None and hit[0] == tag and hit[1].matrix.device == torch.device(device):
+    if hit is not None and hit[0] == tag and hit[1].matrix.device == dev:
         return hit[1]
-    g = Gallery.from_refs(refs, device)
+    g = Gallery.from_refs(refs, dev)
     if len(_gallery_cache) > 8:
         _gallery_cache.clear()
     _gallery_cache[key] = (tag, g)

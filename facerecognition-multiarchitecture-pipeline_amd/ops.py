@@ -6,6 +6,7 @@ Activations are NHWC tensors in the compute dtype (bf16 / fp16); heads and match
 """
 from __future__ import annotations
 
+import functools
 from typing import Optional, Tuple
 
 import torch
@@ -17,7 +18,30 @@ _DT = {torch.bfloat16: BF16, torch.float16: F16}
 
 
 def _stream() -> int:
+    # the CURRENT device's current stream: every public wrapper runs under `_on_operand_device`, which makes the
+    # operands' device current first (HIP's current device is per thread, SURVEY.md §8b threading)
     return torch.cuda.current_stream().cuda_stream
+
+
+def _on_operand_device(fn):
+    """Launch on the device the operands live on, whatever the calling thread's current device is: a model on
+    ``cuda:1`` works from a thread whose current device is ``cuda:0`` (`src/app.py:43` moves the input to
+    ``next(model.parameters()).device``; `:331-335` calls the model from a daemon thread).  Operands on two
+    different GPUs are rejected."""
+    @functools.wraps(fn)
+    def guarded(*args, **kwargs):
+        dev = None
+        for v in args:
+            if isinstance(v, torch.Tensor) and v.is_cuda:
+                if dev is None:
+                    dev = v.device
+                elif v.device != dev:
+                    raise ValueError(f"{fn.__name__}: operands live on different devices ({dev} and {v.device})")
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return guarded
 
 
 def _dev(t: torch.Tensor, what: str, dtype=None) -> torch.Tensor:
@@ -460,3 +484,13 @@ def arcmargin_eval(x: torch.Tensor, w: torch.Tensor, label: torch.Tensor, s: flo
                                                 mm.data_ptr() if want_minmax else 0, ws.data_ptr(), B, Cc, D,
                                                 float(s), float(m), int(easy_margin), _stream()), "arcmargin_eval")
     return out, mm
+
+
+# every tensor-taking wrapper launches on its operands' device (see _on_operand_device)
+for _name in ("pack_input", "pack_conv_weight", "pack_conv_weight_c3", "conv_small_cin", "stem7x7_maxpool", "conv_igemm",
+              "conv_igemm_ds", "linear_mfma", "maxpool", "avgpool_global", "avgpool_adaptive", "linear_f32", "l2_normalize",
+              "cast_to_f32", "cast_from_f32", "add_pos_layernorm", "mha_tokens", "mean_layernorm", "cnn_attention",
+              "normalize_u8", "softmax_argmax", "pairwise_distance", "match_top1", "gap_norm_match", "cosine_logits",
+              "arcmargin_eval"):
+    globals()[_name] = _on_operand_device(globals()[_name])
+del _name

@@ -10,6 +10,7 @@ iteration order, or on which of the reference's aliased key sets (``backbone.*``
 from __future__ import annotations
 
 import math
+import os
 import zlib
 from typing import Dict, Iterable, Mapping, Tuple
 
@@ -105,3 +106,41 @@ def synth_state_dict(shapes: Mapping[str, Tuple[Tuple[int, ...], torch.dtype]], 
 
 def shapes_of(module: torch.nn.Module) -> Dict[str, Tuple[Tuple[int, ...], torch.dtype]]:
     return {k: (tuple(v.shape), v.dtype) for k, v in module.state_dict().items()}
+
+
+# ------------------------------------------------------------------------------------------------
+# BatchNorm-calibrated synthetic weights without a forward pass
+# ------------------------------------------------------------------------------------------------
+# A seeded random-init network maps every input to almost the same embedding (SURVEY.md §7 hard part 2), so the
+# parity tests calibrate each BatchNorm's running statistics on a seeded batch (oracle/weights.py, a CPU forward of
+# the oracle).  The benchmark must run the SAME network the tests check, but the product package may not import the
+# oracle and has no CPU forward of its own: the calibrated statistics of the benchmarked (model, seed) pairs are
+# therefore committed as data (``data/bn_stats_<model>_<seed>.npz``, written by ``oracle/gen_bench_calib.py`` from
+# ``oracle.weights.calibrated_state_dict``; ~40 KB each) and merged into the seeded init here.
+_DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+
+def bn_stats_path(model_type: str, seed: int) -> str:
+    return os.path.join(_DATA_DIR, f"bn_stats_{model_type}_{int(seed)}.npz")
+
+
+def calibrated_state_dict(model_type: str, shapes: Mapping[str, Tuple[Tuple[int, ...], torch.dtype]], seed: int) -> Dict[str, torch.Tensor]:
+    """``synth_state_dict(shapes, seed)`` with every BatchNorm ``running_mean`` / ``running_var`` replaced by the
+    committed calibrated statistics of (model_type, seed).  Raises if that pair has no committed statistics."""
+    path = bn_stats_path(model_type, seed)
+    if not os.path.isfile(path):
+        raise FileNotFoundError(f"no committed BatchNorm statistics for ({model_type!r}, seed {seed}): {path} "
+                                "(generate with `python oracle/gen_bench_calib.py` in the build container)")
+    sd = synth_state_dict(shapes, seed)
+    stats = np.load(path)
+    tp = trunk_prefix_of(sd.keys())
+    for key in sd:
+        if key.endswith("running_mean") or key.endswith("running_var"):
+            ck = canonical_key(key, tp)
+            if ck not in stats.files:
+                raise KeyError(f"{path} has no entry {ck!r}")
+            t = torch.from_numpy(np.asarray(stats[ck], dtype=np.float32))
+            if tuple(t.shape) != tuple(sd[key].shape):
+                raise ValueError(f"{ck}: stored shape {tuple(t.shape)} != {tuple(sd[key].shape)}")
+            sd[key] = t.clone()
+    return sd

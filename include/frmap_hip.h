@@ -15,7 +15,13 @@
  *     gives the text); nothing is thrown across the ABI;
  *   - `dtype`: FRMAP_BF16 or FRMAP_F16 = storage + MFMA input type of activations / packed conv
  *     weights (accumulation is always fp32); heads and matching are fp32 throughout;
- *   - activations are NHWC ("channels last"), C a multiple of 32 for frmap_conv_igemm.
+ *   - activations are NHWC ("channels last"), C a multiple of 32 for frmap_conv_igemm;
+ *   - threading / devices (the reference calls model(x) from a daemon thread while the main thread
+ *     matches, src/app.py:331-335,639): every entry point may be called from any host thread; like
+ *     every HIP launch it targets the calling thread's CURRENT device, so the caller makes the
+ *     device that owns the pointers and `stream` current first (hipSetDevice; the Python binding
+ *     does it per call from the operands' device).  Per-kernel launch attributes are kept per
+ *     (kernel, device), so one process may drive several GPUs.
  */
 #ifndef FRMAP_HIP_H
 #define FRMAP_HIP_H

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Write ``facerecognition-multiarchitecture-pipeline_amd/data/bn_stats_<model>_<seed>.npz``: the BatchNorm running
+statistics of ``oracle.weights.calibrated_state_dict`` for the (model, seed) pairs ``bench.py`` runs, so the benchmark
+measures the same BN-calibrated network the parity tests check without the product importing the oracle.
+
+Test infrastructure (needs only the oracle, not /root/reference):  ``python oracle/gen_bench_calib.py``.
+Only numbers are written: canonical key -> fp32 vector (``features.*`` aliases are folded onto their trunk keys).
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import frmap_amd  # noqa: E402
+import frmap_amd.synth as synth  # noqa: E402
+from oracle import weights  # noqa: E402
+
+PAIRS = [("cnn", weights.SEEDS["cnn"][0]), ("arcface", weights.SEEDS["arcface"][0])]
+
+
+def main():
+    torch.set_num_threads(8)
+    os.makedirs(os.path.dirname(synth.bn_stats_path("x", 0)), exist_ok=True)
+    for mt, seed in PAIRS:
+        model = frmap_amd.get_model(mt, 36)
+        shapes = synth.shapes_of(model)
+        sd = weights.calibrated_state_dict(mt, shapes, seed)
+        tp = synth.trunk_prefix_of(sd.keys())
+        out = {}
+        for k, v in sd.items():
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                ck = synth.canonical_key(k, tp)
+                a = v.detach().cpu().numpy().astype(np.float32)
+                if ck in out:
+                    assert np.array_equal(out[ck], a), (k, ck)
+                out[ck] = a
+        path = synth.bn_stats_path(mt, seed)
+        np.savez_compressed(path, **out)
+        back = synth.calibrated_state_dict(mt, shapes, seed)
+        for k in sd:
+            assert torch.equal(back[k], sd[k]), k
+        print(f"{mt} seed {seed}: {len(out)} BatchNorm statistic vectors -> {path} ({os.path.getsize(path)} bytes)")
+
+
+if __name__ == "__main__":
+    main()
