@@ -62,3 +62,174 @@ def siamese_verify(model, img1: torch.Tensor, img2: torch.Tensor, thresh: float 
     out1, out2 = model(img1, img2)
     dist, same = ops.pairwise_distance(out1, out2, thresh)
     return dist, same.to(torch.float32)
+
+
+# ------------------------------------------------------------------------------------------------
+# §8(f)-2: the batched evaluation harness around the path (`src/testing.py:26-394`)
+# ------------------------------------------------------------------------------------------------
+IMG_EXTENSIONS = ('.jpg', '.jpeg', '.png', '.ppm', '.bmp', '.pgm', '.tif', '.tiff', '.webp')
+
+
+def image_folder(root: str):
+    """``datasets.ImageFolder(root)``'s sample list (`testing.py:110`): classes = sorted sub-directories, samples =
+    every image file under each class directory in sorted walk order.  Returns ``(samples, classes)`` with
+    ``samples = [(path, class_index), ...]``."""
+    import os
+    classes = sorted(d.name for d in os.scandir(root) if d.is_dir())
+    if not classes:
+        raise FileNotFoundError(f"Couldn't find any class folder in {root}.")
+    samples = []
+    for ci, c in enumerate(classes):
+        for r, _, files in sorted(os.walk(os.path.join(root, c), followlinks=True)):
+            for f in sorted(files):
+                if f.lower().endswith(IMG_EXTENSIONS):
+                    samples.append((os.path.join(r, f), ci))
+    return samples, classes
+
+
+def _folder_batches(samples, batch_size, device):
+    from PIL import Image
+    for lo in range(0, len(samples), batch_size):
+        chunk = samples[lo: lo + batch_size]
+        imgs = []
+        for path, _ in chunk:
+            with Image.open(path) as im:
+                imgs.append(im.convert("RGB"))
+        u8 = resize_to_u8(imgs, (224, 224))                                   # transforms.Resize((224, 224)), `testing.py:100`
+        yield preprocess(u8, IMAGENET_MEAN, IMAGENET_STD, device), torch.tensor([c for _, c in chunk], dtype=torch.int64)
+
+
+def _results_file_name(model_type: str) -> str:
+    """`testing.py:369-378`."""
+    return {'siamese': 'siamese_network_results.json', 'arcface': 'arcface_model_results.json',
+            'baseline': 'baseline_model_results.json', 'cnn': 'cnn_model_results.json'}.get(model_type, f'{model_type}_model_results.json')
+
+
+def classification_metrics(all_targets: np.ndarray, all_predictions: np.ndarray, all_probs: np.ndarray, siamese: bool = False) -> dict:
+    """The metric block of `testing.py:290-315` (sklearn, weighted averages, one-vs-rest ROC AUC, average precision;
+    Siamese: curves on ``-distance``).  A metric sklearn cannot define on the given labels (a class with no sample)
+    comes back as NaN instead of aborting the evaluation."""
+    from sklearn.metrics import (accuracy_score, auc, average_precision_score, f1_score, precision_recall_curve,
+                                 precision_score, recall_score, roc_auc_score, roc_curve)
+
+    def safe(fn):
+        try:
+            return float(fn())
+        except Exception:
+            return float("nan")
+
+    m = {"accuracy": safe(lambda: accuracy_score(all_targets, all_predictions)),
+         "precision": safe(lambda: precision_score(all_targets, all_predictions, average='weighted', zero_division=0)),
+         "recall": safe(lambda: recall_score(all_targets, all_predictions, average='weighted', zero_division=0)),
+         "f1": safe(lambda: f1_score(all_targets, all_predictions, average='weighted', zero_division=0))}
+    if siamese:
+        def roc():
+            fpr, tpr, _ = roc_curve(all_targets, -all_probs.ravel())
+            return auc(fpr, tpr)
+
+        def pr():
+            p, r, _ = precision_recall_curve(all_targets, -all_probs.ravel())
+            return auc(r, p)
+        m["roc_auc"], m["pr_auc"] = safe(roc), safe(pr)
+    else:
+        m["roc_auc"] = safe(lambda: roc_auc_score(all_targets, all_probs, multi_class='ovr'))
+        m["pr_auc"] = safe(lambda: average_precision_score(all_targets, all_probs))
+    return m
+
+
+def evaluate_model(model, model_type: str, test_data, class_names: Optional[Sequence[str]] = None,
+                   out_dir: Optional[str] = None, model_name: Optional[str] = None, dataset_name: str = "test",
+                   batch_size: int = 32, arcface_classifier: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                   device="cuda") -> dict:
+    """`src/testing.py:26-394` around the HIP path: batches of 32 → forward → softmax → arg-max → accumulate →
+    sklearn metrics → the same JSON files.  What differs, by necessity: the model (already loaded, on the GPU, in
+    ``eval()``) and the test set are passed in instead of being discovered under ``PROC_DATA_DIR`` / ``CHECKPOINTS_DIR``
+    (`:29-129`, the reference's project layout and interactive prompt — out of scope), and the per-batch "inference
+    time" is bracketed by device synchronisation (the reference's `time.time()` pair at `:164,255-273` times only the
+    asynchronous launches on a GPU).
+
+    ``test_data``: a directory in ``ImageFolder`` layout (class sub-folders; images are resized to 224×224 with PIL
+    and normalised on the device), or an iterable of ready batches — ``(images fp32 NCHW, labels)``, for
+    ``model_type == 'siamese'`` ``(img1, img2, labels)`` (`:170-182`; label 1 = same, prediction = distance < 0.5).
+    ``arcface``: logits = cosine(embedding, class centres) (`:264-269`) unless ``arcface_classifier=(weight, bias)`` is
+    given (the reference scores with a freshly initialised ``nn.Linear(512, C)``, `:134-136,262-263`).
+    Returns the ``model_results`` dict (`:346-362`); with ``out_dir`` also writes ``<type>_model_results.json`` and
+    ``experiment_summary.json`` (`:364-394`)."""
+    import json
+    import os
+    import time
+    if isinstance(test_data, (str, os.PathLike)):
+        if model_type == 'siamese':
+            raise ValueError("siamese evaluation takes an iterable of (img1, img2, labels) batches")
+        samples, classes = image_folder(str(test_data))
+        if not samples:
+            raise FileNotFoundError(f"Found 0 files in subfolders of: {test_data}")
+        class_names = list(classes) if class_names is None else list(class_names)
+        batches = _folder_batches(samples, batch_size, device)
+    else:
+        batches = iter(test_data)
+    if model.training:
+        model.eval()                                                           # `:131`
+    siamese = model_type == 'siamese'
+    all_predictions, all_targets, all_probs, inference_times = [], [], [], []
+    total_loss, nbatches = 0.0, 0
+    with torch.no_grad():
+        for batch in batches:
+            if siamese:
+                img1, img2, labels = batch
+                img1, img2 = img1.to(device), img2.to(device)
+                torch.cuda.synchronize()
+                t0 = time.time()
+                dist, same = siamese_verify(model, img1, img2, 0.5)             # `:175-177`
+                torch.cuda.synchronize()
+                inference_times.append(time.time() - t0)
+                all_predictions.extend(same.cpu().numpy())
+                all_targets.extend(np.asarray(labels.cpu() if isinstance(labels, torch.Tensor) else labels))
+                all_probs.extend(dist.cpu().numpy()[:, None])                    # distances stand in for probabilities (`:182`)
+                nbatches += 1
+                continue
+            images, labels = batch
+            images = images.to(device)
+            labels = torch.as_tensor(labels).to(torch.int64)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            if model_type == 'arcface':
+                emb = model(images)
+                if arcface_classifier is not None:
+                    w, b = arcface_classifier
+                    outputs = ops.linear_f32(emb, w.to(device).float(), None, None if b is None else b.to(device).float())
+                else:
+                    outputs, _ = ops.cosine_logits(emb, model.arcface.weight.detach(), s=1.0, want_argmax=False)
+            else:
+                outputs = model(images)
+            torch.cuda.synchronize()
+            inference_times.append(time.time() - t0)
+            probs, pred = ops.softmax_argmax(outputs)                           # `:278-279`
+            logits = outputs.float().cpu()
+            lse = torch.logsumexp(logits, dim=1)
+            total_loss += float((lse - logits[torch.arange(logits.shape[0]), labels]).mean())   # nn.CrossEntropyLoss, `:275-276`
+            nbatches += 1
+            all_predictions.extend(pred.cpu().numpy())
+            all_targets.extend(labels.numpy())
+            all_probs.extend(probs.cpu().numpy())
+    if nbatches == 0:
+        raise ValueError("evaluate_model: the test set is empty")
+    all_predictions, all_targets, all_probs = np.array(all_predictions), np.array(all_targets), np.array(all_probs)
+    metrics = classification_metrics(all_targets, all_predictions, all_probs, siamese)
+    metrics["inference_time"] = float(np.mean(inference_times))                # `:315`
+    if siamese:
+        class_names = ['Same', 'Different']                                     # `:330`
+    elif class_names is None:
+        class_names = [str(i) for i in range(all_probs.shape[1])]
+    model_results = {"predictions": all_predictions.tolist(), "targets": all_targets.tolist(),
+                     "probabilities": all_probs.tolist(), "class_names": list(class_names), "metrics": metrics}
+    if not siamese:
+        model_results["test_loss"] = total_loss / nbatches                      # printed at `:327`
+    if out_dir is not None:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, _results_file_name(model_type)), 'w') as f:
+            json.dump(model_results, f, indent=2)
+        with open(os.path.join(out_dir, 'experiment_summary.json'), 'w') as f:   # `:384-394`
+            json.dump({"model_type": model_type, "model_name": model_name or model_type, "dataset": dataset_name,
+                       "metrics": metrics, "class_names": list(class_names)}, f, indent=2)
+    return model_results

@@ -326,6 +326,39 @@ def class_centre_match(emb: torch.Tensor, centres: torch.Tensor, s: float = 1.0)
     return logits, logits.argmax(dim=1)
 
 
+def evaluate_loop(model_type: str, sd: SD, batches, arcface_classifier=None) -> dict:
+    """The evaluation loop of `src/testing.py:167-283` restated on the CPU: per batch forward -> (ArcFace: classifier
+    or cosine vs class centres, `:258-269`) -> CrossEntropyLoss (`:275-276`) -> softmax -> arg-max (`:278-279`);
+    Siamese: ``pairwise_distance`` -> ``dist < 0.5`` (`:175-177`), distances collected as ``[d]`` rows (`:182`).
+    Returns predictions / targets / probabilities (numpy) and the mean loss, as the reference accumulates them."""
+    import numpy as np
+    preds, targets, probs, total_loss, n = [], [], [], 0.0, 0
+    with torch.no_grad():
+        for batch in batches:
+            if model_type == "siamese":
+                x1, x2, labels = batch
+                dist, pred = siamese_decision(*siamese_forward(sd, x1, x2))
+                preds.extend(pred.numpy()); targets.extend(labels.numpy()); probs.extend(dist.numpy()[:, None])
+                n += 1
+                continue
+            x, labels = batch
+            if model_type == "arcface":
+                emb = arcface_embedding(sd, x)
+                if arcface_classifier is not None:
+                    outputs = F.linear(emb, arcface_classifier[0], arcface_classifier[1])
+                else:
+                    outputs = F.linear(F.normalize(emb), F.normalize(sd["arcface.weight"]))
+            else:
+                outputs = FORWARD[model_type](sd, x)
+            total_loss += float(F.cross_entropy(outputs, labels))
+            p = F.softmax(outputs, dim=1)
+            _, predicted = torch.max(outputs, 1)
+            preds.extend(predicted.numpy()); targets.extend(labels.numpy()); probs.extend(p.numpy())
+            n += 1
+    return {"predictions": np.array(preds), "targets": np.array(targets), "probabilities": np.array(probs),
+            "test_loss": total_loss / max(n, 1), "logit_batches": n}
+
+
 # --------------------------------------------------------------------------------------------
 # dispatch by reference model_type (face_models.py:785-813)
 # --------------------------------------------------------------------------------------------

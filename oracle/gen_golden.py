@@ -7,8 +7,9 @@ What runs the reference's own code: every ``forward`` / ``get_embedding`` / ``Ar
 output below comes from classes defined in ``/root/reference/src/face_models.py`` (loaded by
 ``oracle/ref_loader.py``; only the un-vendored ``torchvision.models.resnet18`` is a stub).
 ``src/app.py`` cannot be imported here (streamlit / cv2 / facenet_pytorch / torchvision are absent),
-so the ``compare_faces`` known answers are produced by ``face_oracle.compare_faces``, a
-line-by-line restatement of `src/app.py:50-64` built on the same ``F.pairwise_distance``.
+but `compare_faces` (`src/app.py:50-64`) needs only ``torch``: ``ref_loader.reference_compare_faces`` compiles that
+one function from the reference file and every ``compare_faces`` known answer below (``face_references.json``,
+``match.npz``) is produced by EXECUTING it; ``face_oracle.compare_faces`` is asserted equal to it on the way.
 
 Only numbers are written (npz / json): inputs are regenerated from seeds on both sides; weights are
 regenerated from seeds + the calibration pass (``oracle/weights.py``).  No reference source text is
@@ -138,7 +139,11 @@ def gen_arcmargin(ref):
     np.savez_compressed(os.path.join(GOLD, "arcmargin.npz"), **out)
 
 
-def gen_gallery():
+def _same_answer(a, b):
+    return a[0] == b[0] and a[2] == b[2] and (a[1] == b[1] or abs(a[1] - b[1]) <= 1e-7 * max(1.0, abs(a[1])))
+
+
+def gen_gallery(ref_cf):
     recs = gallery_io.read_gallery_file("/root/reference/face_references/face_references.pkl")
     names = [r["name"] for r in recs]
     emb = np.concatenate([r["embedding_numpy"] for r in recs], axis=0).astype(np.float32)
@@ -148,10 +153,17 @@ def gen_gallery():
     for i in range(G):
         for j in range(G):
             dmat[i, j] = F.pairwise_distance(refs[i]["embedding"], refs[j]["embedding"]).item()
-    full = [list(fo.compare_faces(refs[i]["embedding"], refs, 1.0)) for i in range(G)]
-    loo = [list(fo.compare_faces(refs[i]["embedding"], refs[:i] + refs[i + 1:], 1.0)) for i in range(G)]
-    loo2 = [list(fo.compare_faces(refs[i]["embedding"], refs[:i] + refs[i + 1:], 2.0)) for i in range(G)]
+    full = [list(ref_cf(refs[i]["embedding"], refs, 1.0)) for i in range(G)]
+    loo = [list(ref_cf(refs[i]["embedding"], refs[:i] + refs[i + 1:], 1.0)) for i in range(G)]
+    loo2 = [list(ref_cf(refs[i]["embedding"], refs[:i] + refs[i + 1:], 2.0)) for i in range(G)]
+    for i in range(G):   # the restatement must agree with the function it restates
+        assert _same_answer(fo.compare_faces(refs[i]["embedding"], refs, 1.0), full[i])
+        assert _same_answer(fo.compare_faces(refs[i]["embedding"], refs[:i] + refs[i + 1:], 1.0), loo[i])
+        assert _same_answer(fo.compare_faces(refs[i]["embedding"], refs[:i] + refs[i + 1:], 2.0), loo2[i])
+    assert ref_cf(None, refs, 1.0) == fo.compare_faces(None, refs, 1.0) == ("Unknown", float("inf"), None)
+    assert ref_cf(refs[0]["embedding"], [], 1.0) == fo.compare_faces(refs[0]["embedding"], [], 1.0)
     doc = {"source": "face_references/face_references.pkl (read with the non-executing parser)",
+           "answers_by": "the reference's own compare_faces (src/app.py:50-64), executed in the build container",
            "names": names, "image_paths": [r["image_path"] for r in recs],
            "embeddings": [[float(v) for v in row] for row in emb],
            "pairwise_distance": [[float(v) for v in row] for row in dmat],
@@ -161,7 +173,7 @@ def gen_gallery():
         json.dump(doc, f)
 
 
-def gen_match():
+def gen_match(ref_cf):
     out = {}
     for G in (36, 1000):
         gal = synth.unit_rows(3000 + G, G, 512)
@@ -174,7 +186,8 @@ def gen_match():
             refs = [{"name": f"id{i}", "embedding": gal[i:i + 1]} for i in range(G)]
             ids, dists, margins = [], [], []
             for b in range(16):
-                name, d, idx = fo.compare_faces(probes[b:b + 1], refs, 1e9)
+                name, d, idx = ref_cf(probes[b:b + 1], refs, 1e9)
+                assert _same_answer(fo.compare_faces(probes[b:b + 1], refs, 1e9), (name, d, idx))
                 alld = torch.stack([F.pairwise_distance(probes[b:b + 1], r["embedding"])[0] for r in refs])
                 top2 = torch.topk(alld, 2, largest=False).values
                 ids.append(idx); dists.append(d); margins.append(float(top2[1] - top2[0]))
@@ -191,8 +204,9 @@ def main():
     ref = ref_loader.load_reference()
     only = set(sys.argv[1:])  # e.g. `gen_golden.py attention ensemble` regenerates just those files
     if not only:
-        gen_gallery()
-        gen_match()
+        ref_cf = ref_loader.reference_compare_faces()
+        gen_gallery(ref_cf)
+        gen_match(ref_cf)
         gen_arcmargin(ref)
     if not only or "ensemble" in only:
         gen_ensemble(ref)

@@ -115,3 +115,29 @@ def load_reference():
         sys.dont_write_bytecode = old
     _cached = mod
     return mod
+
+
+APP_FILE = "/root/reference/src/app.py"
+
+
+def load_reference_function(path: str, name: str, namespace: dict):
+    """Return the reference's own top-level function ``name`` of ``path``, compiled from its source in the build
+    container WITHOUT importing the module around it (``src/app.py`` imports streamlit / cv2 / facenet_pytorch at
+    module level, none of which exist here): the file is parsed, the one ``FunctionDef`` node is compiled on its own
+    and executed in ``namespace`` (the globals it needs, e.g. ``{"torch": torch}``).  Nothing is written anywhere;
+    the reference's text never leaves the container."""
+    import ast
+    with open(path, "r", encoding="utf-8") as f:
+        tree = ast.parse(f.read(), filename=path)
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name == name:
+            mod = ast.Module(body=[node], type_ignores=[])
+            ns = dict(namespace)
+            exec(compile(mod, path, "exec"), ns)
+            return ns[name]
+    raise LookupError(f"{path} has no top-level function {name!r}")
+
+
+def reference_compare_faces():
+    """`src/app.py:50-64` itself (needs only ``torch``)."""
+    return load_reference_function(APP_FILE, "compare_faces", {"torch": torch})

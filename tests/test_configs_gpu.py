@@ -1,0 +1,272 @@
+"""GPU: BASELINE.json's configs at their FULL sizes against the CPU oracle, through the code paths the benchmark times.
+
+  config 2  cnn, bf16, B = 256, 36-ID gallery: `embed_and_match` (the fused pool + normalise + match tail) and
+            `GraphedEmbedMatch` (HIP-graph replay, 2 micro-batch streams) on the full batch; the first 32 faces
+            are checked against oracle `cnn_embedding -> normalize -> compare_faces` (enrolment-style gallery:
+            probes are perturbed copies of enrolled faces, so top-1 has a real answer), top-1 identical and
+            the distance within a stated bound; the other 224 faces through per-face independence.
+  config 3  ArcMarginProduct eval head, B = 1024 x 1000 IDs, directly against the oracle restatement of
+            `face_models.py:351-429` (whose known answers are the reference class's, tests/golden/arcmargin.npz).
+  config 5  hybrid, bf16, B = 256 per GPU: 16 oracle rows + per-face independence at the full batch.
+  boundary  the reference's threading pattern (`src/app.py:331-335,639`): a daemon thread runs model(x) in a
+            loop while the main thread runs compare_faces; results equal the single-threaded ones.
+"""
+import math
+import queue
+import threading
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import frmap_amd  # noqa: E402
+from frmap_amd import ops, synth  # noqa: E402
+from oracle import face_oracle as fo  # noqa: E402
+from oracle import weights  # noqa: E402
+
+DEV = "cuda"
+
+
+def _model(mt, sd, dtype):
+    m = frmap_amd.get_model(mt, 36)
+    m.load_state_dict(sd)
+    return m.to(DEV).eval().set_compute_dtype(dtype)
+
+
+# measured on MI355X (printed by the test): bf16 max |d - d_oracle| 1.0e-2 .. 1.6e-2, fp16 < 2e-3; bound = ~2x
+DIST_BOUND = {torch.bfloat16: 3.5e-2, torch.float16: 5e-3}
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_config2_cnn_b256_top1_and_distance_vs_oracle(dtype, calibrated_sd):
+    sd = calibrated_sd("cnn")
+    enrol = synth.randn(7101, (36, 3, 224, 224), "enrol2")
+    probes = enrol[:32] + 0.02 * synth.randn(7102, (32, 3, 224, 224), "pert2")
+    fill = synth.randn(7103, (224, 3, 224, 224), "fill2")
+    with torch.no_grad():
+        gal = F.normalize(fo.cnn_embedding(sd, enrol), dim=1)                 # oracle enrolment
+        ref_emb = F.normalize(fo.cnn_embedding(sd, probes), dim=1)
+    refs = [{"name": f"id{i}", "embedding": gal[i:i + 1]} for i in range(36)]
+    ref_ans = [fo.compare_faces(ref_emb[i:i + 1], refs, 1.0) for i in range(32)]
+    assert [a[2] for a in ref_ans] == list(range(32))                          # every probe finds its own enrolment
+    d_all = torch.cdist(ref_emb, gal)
+    margin = float((d_all.sort(dim=1).values[:, 1] - d_all.sort(dim=1).values[:, 0]).min())
+    assert margin > 4 * DIST_BOUND[dtype], margin                              # the top-1 answer is not a coin flip
+
+    m = _model("cnn", sd, dtype)
+    g = frmap_amd.Gallery([f"id{i}" for i in range(36)], gal, DEV)
+    x = torch.cat([probes, fill]).to(DEV)                                       # the benchmark's batch: 256 faces
+    assert x.shape[0] == 256
+    with torch.no_grad():
+        ids, dists = frmap_amd.embed_and_match(m, x, g, 1.0, normalize=True)    # fused gap_norm_match tail
+        pipe = frmap_amd.GraphedEmbedMatch(m, g, x.clone(), 1.0, normalize=True, streams=2)
+        pipe()
+        torch.cuda.synchronize()
+        ids_g, dists_g = pipe.ids().clone(), pipe.dists().clone()
+        ids_half, dists_half = frmap_amd.embed_and_match(m, x[128:], g, 1.0, normalize=True)
+    want_ids = torch.tensor([a[2] for a in ref_ans], dtype=torch.int32)
+    want_d = torch.tensor([a[1] for a in ref_ans])
+    for name, i_, d_ in (("embed_and_match", ids, dists), ("GraphedEmbedMatch", ids_g, dists_g)):
+        err = float((d_[:32].cpu() - want_d).abs().max())
+        print(f"config 2 {dtype} {name}: top-1 {'identical' if torch.equal(i_[:32].cpu(), want_ids) else 'DIFFERS'}, "
+              f"max |dist - oracle| = {err:.2e} (oracle margin {margin:.3f})")
+        assert torch.equal(i_[:32].cpu(), want_ids), name
+        assert err < DIST_BOUND[dtype], (name, err)
+    # graph replay (2 micro-batches of 128 on 2 streams) == eager full batch == a 128-face sub-batch, bit for bit
+    assert torch.equal(ids_g, ids) and torch.equal(dists_g, dists)
+    assert torch.equal(ids_half, ids[128:]) and torch.equal(dists_half, dists[128:])
+
+
+def test_config3_arcmargin_head_full_size():
+    """B = 1024 embeddings x 1000 class centres, s = 30, m = 0.5 (BASELINE.json configs[2]) in fp32, and the
+    label-free cosine top-1 of the same shapes."""
+    B, D, C = 1024, 512, 1000
+    w = synth.randn(1003, (C, D), tag="arcmargin.weight")
+    x = synth.randn(2003, (B, D), tag="cfg3.x")
+    lab = torch.from_numpy(np.random.Generator(np.random.PCG64(4003)).integers(0, C, B)).long()
+    want = fo.arcmargin_eval(w, x, lab, s=30.0, m=0.5)
+    out, mm = ops.arcmargin_eval(x.to(DEV), w.to(DEV), lab.to(DEV), 30.0, 0.5, want_minmax=True)
+    err = float((out.cpu() - want).abs().max())
+    print(f"config 3: max |logit - oracle| = {err:.2e}")
+    assert err < 2e-4                                                          # fp32 MFMA vs fp32 CPU, scale 24
+    cos = F.linear(F.normalize(x), F.normalize(w))
+    assert abs(float(mm[0]) - float(cos.max())) < 1e-5 and abs(float(mm[1]) - float(cos.min())) < 1e-5
+    logits, arg = ops.cosine_logits(x.to(DEV), w.to(DEV), s=1.0)
+    rl, ra = fo.class_centre_match(x, w, 1.0)
+    assert float((logits.cpu() - rl).abs().max()) < 1e-5
+    top2 = rl.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 1e-5
+    assert torch.equal(arg.cpu()[safe].long(), ra[safe]) and int(safe.sum()) > 1000
+    head = frmap_amd.ArcMarginProduct(D, C, s=30.0, m=0.5).to(DEV).eval()
+    with torch.no_grad():
+        head.weight.copy_(w.to(DEV))
+        assert float((head(x.to(DEV), lab.to(DEV)).cpu() - want).abs().max()) < 2e-4
+    st = head.get_margin_stats()
+    assert abs(st["max_cos_theta"] - float(cos.max())) < 1e-5
+
+
+def test_config5_hybrid_b256(calibrated_sd):
+    sd = calibrated_sd("hybrid")
+    x16 = weights.golden_inputs("hybrid")                                       # 16 faces with oracle rows
+    fill = synth.randn(7201, (240, 3, 224, 224), "fill5")
+    with torch.no_grad():
+        want = fo.hybrid_embedding(sd, x16)
+    m = _model("hybrid", sd, torch.bfloat16)
+    x = torch.cat([x16, fill]).to(DEV)
+    with torch.no_grad():
+        e = m.get_embedding(x)
+        assert e.shape == (256, 512) and torch.isfinite(e).all()
+        cosdev = float((1 - F.cosine_similarity(e[:16].float().cpu(), want, dim=1)).max())
+        rel = float((e[:16].float().cpu() - want).norm() / want.norm())
+        print(f"config 5 hybrid bf16 B=256: max 1-cos {cosdev:.2e}, rel-L2 {rel:.2e}")
+        assert cosdev < 6e-3 and rel < 8e-2                                    # measured 2.3e-3 / 3.6e-2 (bf16)
+        for lo, hi in ((0, 16), (100, 101), (250, 256)):                      # per-face independence at the full batch
+            assert torch.equal(m.get_embedding(x[lo:hi]).reshape(hi - lo, 512), e[lo:hi]), (lo, hi)
+        assert m(x).shape == (256, 36)
+
+
+def test_large_gallery_duplicate_rows_return_first():
+    """`app.py:58-62` keeps the FIRST strict minimum.  The large-gallery path (G > 64) takes the arg-min from the
+    expanded form on the MFMA; identical rows give bit-identical scores and the (score, index) key keeps the lower
+    index, so duplicates resolve as the reference's loop does."""
+    G, D = 1000, 512
+    gal = synth.unit_rows(3301, G, D)
+    gal[700] = gal[3]
+    gal[901] = gal[900]
+    gal[64] = gal[63]
+    probes = torch.cat([gal[[3, 900, 63, 700, 901, 64]], F.normalize(gal[[3, 900]] + 0.01 * synth.randn(3302, (2, D), "n"), dim=1)])
+    idx, dist = ops.match_top1(probes.to(DEV), gal.to(DEV))
+    assert idx.cpu().tolist() == [3, 900, 63, 3, 900, 63, 3, 900]
+    want_i, want_d = fo.match_top1(probes, gal)
+    assert want_i.tolist() == idx.cpu().tolist() and torch.allclose(dist.cpu(), want_d, atol=1e-5)
+
+
+def test_daemon_thread_forward_beside_main_thread_matching(calibrated_sd):
+    """`src/app.py:331-335` -> `:236` -> `:44`: model(x) runs on a daemon thread, results cross a queue.Queue;
+    the main thread calls compare_faces (`:639`) meanwhile.  Same answers as the single-threaded calls."""
+    sd = calibrated_sd("arcface")
+    m = _model("arcface", sd, torch.float16)
+    x = weights.golden_inputs("arcface", 8).to(DEV)
+    gal = synth.unit_rows(3001, 36, 512)
+    refs = [{"name": f"id{i}", "embedding": gal[i:i + 1]} for i in range(36)]
+    with torch.no_grad():
+        base = [m(x[i:i + 1]).clone() for i in range(8)]
+        base_ans = [frmap_amd.compare_faces(e, refs, 2.0) for e in base]
+    torch.cuda.synchronize()
+    q, errors, stop = queue.Queue(), [], threading.Event()
+
+    def producer():
+        try:
+            with torch.no_grad():
+                for rep in range(6):
+                    for i in range(8):
+                        if stop.is_set():
+                            return
+                        q.put((i, m(x[i:i + 1])))
+        except Exception as e:  # surfaced on the main thread
+            errors.append(e)
+        finally:
+            q.put(None)
+
+    t = threading.Thread(target=producer, daemon=True)
+    t.start()
+    n = 0
+    try:
+        while True:
+            item = q.get(timeout=120)
+            if item is None:
+                break
+            i, emb = item
+            assert torch.equal(emb, base[i]), i                               # the forward is unaffected by the other thread
+            assert frmap_amd.compare_faces(emb, refs, 2.0) == base_ans[i], i
+            n += 1
+    finally:
+        stop.set()
+        t.join(60)
+    assert not errors, errors
+    assert n == 48
+
+
+def test_operands_on_one_device_and_launch_on_their_device():
+    a = torch.zeros((2, 8), device=DEV)
+    assert torch.equal(ops.l2_normalize(a), a)
+    if torch.cuda.device_count() > 1:                                         # multi-GPU hosts only
+        b = synth.unit_rows(5, 4, 512).to("cuda:1")
+        with torch.cuda.device(0):
+            out = ops.l2_normalize(b * 3)                                      # current device 0, operands on 1
+        assert out.device == b.device and torch.allclose(out.cpu(), b.cpu(), atol=1e-6)
+        with pytest.raises(ValueError, match="different devices"):
+            ops.match_top1(b, synth.unit_rows(6, 3, 512).to("cuda:0"))
+
+
+def test_evaluate_model_harness_on_synthetic_folders(tmp_path, calibrated_sd):
+    """§8(f)-2: `evaluate.evaluate_model` (the loop + metrics + JSON of `src/testing.py:26-394`) on a synthetic
+    ImageFolder (5 classes x 9 PNG files of assorted sizes; 45 images = one full batch of 32 + a ragged one) against
+    the oracle's restatement of the loop on the same resized pixels."""
+    import json
+    from PIL import Image
+    from frmap_amd import evaluate
+    g = np.random.Generator(np.random.PCG64(99))
+    root = tmp_path / "test"
+    for c in range(5):
+        d = root / f"person_{c:02d}"
+        d.mkdir(parents=True)
+        for i in range(9):
+            h, w = int(g.integers(120, 300)), int(g.integers(120, 300))
+            Image.fromarray(g.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(d / f"img_{i}.png")
+    samples, classes = evaluate.image_folder(str(root))
+    assert classes == [f"person_{c:02d}" for c in range(5)] and len(samples) == 45
+    assert [s[1] for s in samples] == sorted(s[1] for s in samples)
+
+    def cpu_batches():
+        for lo in range(0, 45, 32):
+            chunk = samples[lo: lo + 32]
+            u8 = evaluate.resize_to_u8([Image.open(p) for p, _ in chunk])
+            x = (u8.permute(0, 3, 1, 2).float() / 255 - torch.tensor(evaluate.IMAGENET_MEAN).view(1, 3, 1, 1)) / torch.tensor(evaluate.IMAGENET_STD).view(1, 3, 1, 1)
+            yield x, torch.tensor([c for _, c in chunk])
+
+    for mt in ("baseline", "arcface"):
+        sd = calibrated_sd(mt)
+        m = _model(mt, sd, torch.float16)
+        out = tmp_path / f"out_{mt}"
+        res = evaluate.evaluate_model(m, mt, str(root), out_dir=str(out), model_name=f"{mt}_v1", dataset_name="synthetic")
+        ref = fo.evaluate_loop(mt, sd, cpu_batches())
+        probs, rprobs = np.array(res["probabilities"]), ref["probabilities"]
+        assert probs.shape == rprobs.shape == (45, 36) and res["targets"] == ref["targets"].tolist()
+        assert np.abs(probs - rprobs).max() < 3e-3
+        top2 = np.sort(rprobs, axis=1)[:, -2:]
+        safe = (top2[:, 1] - top2[:, 0]) > 6e-3                                 # decisions fp16 cannot flip
+        assert (np.array(res["predictions"])[safe] == ref["predictions"][safe]).all() and safe.sum() >= 20
+        assert abs(res["test_loss"] - ref["test_loss"]) < 5e-3
+        want = evaluate.classification_metrics(ref["targets"], np.array(res["predictions"]), rprobs)
+        for k in ("accuracy", "precision", "recall", "f1"):
+            assert res["metrics"][k] == pytest.approx(want[k], abs=1e-9)
+        assert set(res["metrics"]) == {"accuracy", "precision", "recall", "f1", "roc_auc", "pr_auc", "inference_time"}
+        assert res["metrics"]["inference_time"] > 0 and res["class_names"] == classes
+        doc = json.load(open(out / f"{mt}_model_results.json" if mt not in ("arcface",) else out / "arcface_model_results.json"))
+        assert set(doc) >= {"predictions", "targets", "probabilities", "class_names", "metrics"}       # `testing.py:346-362`
+        summ = json.load(open(out / "experiment_summary.json"))
+        assert summ["model_type"] == mt and summ["model_name"] == f"{mt}_v1" and summ["dataset"] == "synthetic"
+    # ArcFace with an explicit classifier (`testing.py:134-136,262-263`)
+    sd = calibrated_sd("arcface")
+    m = _model("arcface", sd, torch.float16)
+    w, b = synth.randn(31, (36, 512), "clsw") * 0.05, synth.randn(32, (36,), "clsb") * 0.01
+    res = evaluate.evaluate_model(m, "arcface", str(root), arcface_classifier=(w, b))
+    ref = fo.evaluate_loop("arcface", sd, cpu_batches(), arcface_classifier=(w, b))
+    assert np.abs(np.array(res["probabilities"]) - ref["probabilities"]).max() < 3e-3
+    # Siamese pairs (`testing.py:170-182`)
+    sd = calibrated_sd("siamese")
+    m = _model("siamese", sd, torch.float16)
+    x = weights.golden_inputs("siamese", 12)
+    lab = torch.tensor([1, 0, 1, 0, 1, 0])
+    pairs = [(x[:4], x[4:8], lab[:4]), (x[8:10], x[10:12], lab[4:])]
+    res = evaluate.evaluate_model(m, "siamese", [(a.to(DEV), b_.to(DEV), l) for a, b_, l in pairs], out_dir=str(tmp_path / "s"))
+    ref = fo.evaluate_loop("siamese", sd, pairs)
+    assert np.abs(np.array(res["probabilities"]) - ref["probabilities"]).max() < 2e-2
+    assert res["predictions"] == ref["predictions"].tolist() and res["class_names"] == ["Same", "Different"]
+    assert (tmp_path / "s" / "siamese_network_results.json").exists()
+    with pytest.raises(FileNotFoundError):
+        evaluate.evaluate_model(m, "baseline", str(tmp_path / "nope_empty_dir_missing"))
