@@ -36,8 +36,8 @@ def _model(mt, sd, dtype):
     return m.to(DEV).eval().set_compute_dtype(dtype)
 
 
-# measured on MI355X (printed by the test): bf16 max |d - d_oracle| 1.0e-2 .. 1.6e-2, fp16 < 2e-3; bound = ~2x
-DIST_BOUND = {torch.bfloat16: 3.5e-2, torch.float16: 5e-3}
+# measured on MI355X (printed by the test): max |d - d_oracle| = 2.1e-3 (bf16), 1.3e-4 (fp16); bound = ~2.5x
+DIST_BOUND = {torch.bfloat16: 5e-3, torch.float16: 3.5e-4}
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -122,9 +122,13 @@ def test_config5_hybrid_b256(calibrated_sd):
         cosdev = float((1 - F.cosine_similarity(e[:16].float().cpu(), want, dim=1)).max())
         rel = float((e[:16].float().cpu() - want).norm() / want.norm())
         print(f"config 5 hybrid bf16 B=256: max 1-cos {cosdev:.2e}, rel-L2 {rel:.2e}")
-        assert cosdev < 6e-3 and rel < 8e-2                                    # measured 2.3e-3 / 3.6e-2 (bf16)
-        for lo, hi in ((0, 16), (100, 101), (250, 256)):                      # per-face independence at the full batch
-            assert torch.equal(m.get_embedding(x[lo:hi]).reshape(hi - lo, 512), e[lo:hi]), (lo, hi)
+        assert cosdev < 2e-3 and rel < 7e-2                                    # measured 7.9e-4 / 3.3e-2 (bf16)
+        # per-face independence at the full batch.  Not bit-exact for this model: the token GEMMs pick their split-K
+        # factor from the row count (frmap_linear_mfma), so the fp32 summation order differs between batch sizes.
+        for lo, hi in ((0, 16), (100, 101), (250, 256)):
+            sub = m.get_embedding(x[lo:hi]).reshape(hi - lo, 512)
+            assert float((1 - F.cosine_similarity(sub.float(), e[lo:hi].float(), dim=1)).max()) < 1e-4, (lo, hi)
+            assert float((sub.float() - e[lo:hi].float()).abs().max()) < 5e-2, (lo, hi)
         assert m(x).shape == (256, 36)
 
 

@@ -1,9 +1,9 @@
 """GPU: whole-model parity of the HIP path (through get_model / forward / get_embedding /
 compare_faces) against the committed reference goldens and the CPU oracle, same seeded inputs.
 
-Tolerances (north star): fp16 — embedding 1-cos <= 1e-3 and top-1 identical; bf16 — measured
-deviation reported, bound 1e-2 (bf16 cannot meet 1e-3 on decorrelated embeddings, SURVEY.md §7
-hard part 3).  Non-normalised / non-negative embeddings (baseline, cnn) are compared by relative L2
+Tolerances (north star): fp16 — embedding 1-cos <= 1e-3 and top-1 identical (measured 2e-5 .. 4e-4);
+bf16 — the measured deviation (1.3e-3 .. 2e-2 mean-centred: bf16 cannot meet 1e-3 on decorrelated embeddings,
+SURVEY.md §7 hard part 3) is gated at 2.5x its measured value per model (table MEASURED).  Non-normalised / non-negative embeddings (baseline, cnn) are compared by relative L2
 and by cosine after removing the batch mean (raw cosine is ~1 for any output there)."""
 import json
 import os
@@ -21,7 +21,19 @@ from oracle import face_oracle as fo  # noqa: E402
 from oracle import weights  # noqa: E402
 
 DEV = "cuda"
-TOL = {torch.float16: dict(cos=1e-3, rel=1.5e-2), torch.bfloat16: dict(cos=1e-2, rel=6e-2)}
+TOL = {torch.float16: dict(cos=1e-3, rel=1.5e-2), torch.bfloat16: dict(cos=1e-2, rel=6e-2)}   # forward()/unit-embedding checks
+# Embedding deviation from the reference goldens as measured on MI355X (round 2, printed by the test):
+# (relative L2, max mean-centred 1-cos).  The gate is 2.5x the measured value, so a regression of the arithmetic
+# (an accumulation in 16 bits, a dropped rounding step) fails here long before it reaches the north-star bounds.
+MEASURED = {
+    ("baseline", torch.float16): (5.1e-4, 3.9e-4), ("baseline", torch.bfloat16): (3.7e-3, 2.0e-2),
+    ("cnn", torch.float16): (1.1e-3, 3.0e-5), ("cnn", torch.bfloat16): (8.8e-3, 1.8e-3),
+    ("arcface", torch.float16): (6.3e-3, 3.2e-5), ("arcface", torch.bfloat16): (5.0e-2, 1.8e-3),
+    ("siamese", torch.float16): (4.3e-3, 2.2e-5), ("siamese", torch.bfloat16): (3.2e-2, 1.3e-3),
+    ("hybrid", torch.float16): (4.1e-3, 6.0e-5), ("hybrid", torch.bfloat16): (3.3e-2, 4.2e-3),
+    ("attention", torch.float16): (2.8e-3, 1.6e-4), ("attention", torch.bfloat16): (2.4e-2, 9.1e-3),
+}
+GATE = 2.5
 
 
 def _model(mt, sd, dtype):
@@ -52,8 +64,9 @@ def test_model_parity(mt, dtype, gold_dir, calibrated_sd):
         rel = float((emb - ref).norm() / ref.norm())
         cosdev = float((1 - _centered_cos(emb, ref)).max())
         print(f"{mt} {dtype} vs {name}: rel-L2 {rel:.2e}  max(1-cos centred) {cosdev:.2e}")
-        assert rel < tol["rel"], (name, rel)
-        assert cosdev < tol["cos"] * (1 if mt in ("arcface", "siamese", "hybrid") else 10), (name, cosdev)
+        m_rel, m_cos = MEASURED[(mt, dtype)]
+        assert rel < GATE * m_rel, (name, rel, m_rel)
+        assert cosdev < GATE * m_cos, (name, cosdev, m_cos)
     if mt in ("arcface", "siamese"):
         assert float((1 - F.cosine_similarity(emb, gold, dim=1)).max()) < tol["cos"]
         assert torch.allclose(emb.norm(dim=1), torch.ones(emb.shape[0]), atol=1e-4)
