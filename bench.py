@@ -292,7 +292,10 @@ def worker(args) -> int:
     gallery = frmap_amd.Gallery([f"id{i}" for i in range(G)], synth.unit_rows(seeds[2], G, D), dev)
     gen = torch.Generator(device=dev)
     gen.manual_seed(seeds[1] + rank)
-    x = torch.randn((B, 3, 224, 224), device=dev, dtype=torch.float32, generator=gen)  # resident in HBM
+    if args.input == "u8":   # uint8 HWC crops; ToTensor + Normalize happen inside the stem
+        x = torch.randint(0, 256, (B, 224, 224, 3), device=dev, dtype=torch.uint8, generator=gen)
+    else:
+        x = torch.randn((B, 3, 224, 224), device=dev, dtype=torch.float32, generator=gen)  # resident in HBM
     need_norm = model_type in ("cnn", "baseline", "hybrid", "attention")
     total = B * world
 
@@ -465,7 +468,7 @@ def worker(args) -> int:
                 t16 = timed_region(rec16, 50, args.warmup, args.steps, False)
                 extras["fp16_value"] = round(B * args.steps / t16, 1)
                 del m16, rec16
-            if getattr(model, "supports_u8_input", False):
+            if getattr(model, "supports_u8_input", False) and args.input == "f32":
                 gen8 = torch.Generator(device=dev)
                 gen8.manual_seed(seeds[1] + 77)
                 x8 = torch.randint(0, 256, (B, 224, 224, 3), device=dev, dtype=torch.uint8, generator=gen8)
@@ -491,6 +494,9 @@ def worker(args) -> int:
         torch.set_num_threads(cores)
         nb = 64
         xc = x[:nb].cpu()
+        if xc.dtype == torch.uint8:   # the reference's ToTensor + Normalize (`src/testing.py:99-104`) on the host
+            mean, std = torch.tensor(model.input_mean).view(1, 3, 1, 1), torch.tensor(model.input_std).view(1, 3, 1, 1)
+            xc = (xc.permute(0, 3, 1, 2).float() / 255.0 - mean) / std
         gal = gallery.matrix.cpu()
         emb_fn = {"cnn": fo.cnn_embedding, "arcface": fo.arcface_embedding, "baseline": fo.baseline_embedding,
                   "siamese": fo.siamese_forward_one, "hybrid": fo.hybrid_embedding,
@@ -517,7 +523,7 @@ def worker(args) -> int:
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{names.get(model_type, model_type)} embed + L2-normalise + top-1 match, batch {B}/GPU, "
-                                   f"{G}-ID gallery, 224x224x3 fp32 NCHW inputs resident in HBM, seeded random-init weights "
+                                   f"{G}-ID gallery, 224x224x3 " + ("fp32 NCHW" if args.input == "f32" else "uint8 HWC") + " inputs resident in HBM, seeded random-init weights "
                                    f"with calibrated BatchNorm statistics (BASELINE.json configs[{3 if model_type == 'arcface' and G >= 10000 else 1}])",
                        "global_batch": total,
                        "parallelism": f"dp{world} (faces sharded, 1 all-gather of 8 B/face" + (", overlapped with the next step" if overlap else "") + ")",

@@ -31,6 +31,7 @@ PROTOTYPES = {
     "frmap_conv_small_cin": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "frmap_stem7x7_maxpool": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "frmap_stem7x7_maxpool2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "frmap_stem7x7_maxpool_u8": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "frmap_conv_igemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "frmap_conv_igemm_ds_supported": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "frmap_conv_igemm_ds": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -20,9 +20,12 @@
 // Recompute: 7/6 rows x 16/14 columns = 1.33x the stem's MACs (6.5 % of the network), paid to drop
 // 3.2 MB/face of HBM traffic and two launches.
 #include "frmap_common.h"
+#include <stdlib.h>
 
 struct StemPoolParams {
-  const float* x;
+  const float* x;           // fp32 NCHW input (U8 = false)
+  const unsigned char* x8;  // uint8 HWC RGB input (U8 = true): ToTensor + Normalize(mean, std) happen at staging time
+  float mean[3], std[3];
   const void* wpk;
   const float* shift;
   void* out;
@@ -50,7 +53,17 @@ __device__ __forceinline__ float row_down(float v) {
 // VEC4: the input rows are staged with 16-byte loads (4 pixels of one colour plane per lane and load; needs
 // W % 4 == 0 and a 16-byte aligned tensor): 9 loads per thread and tile instead of 30 dword loads, which
 // took ~70 cycles each to issue on the vector-memory path.
-template <typename TT, bool POOL3, bool VEC4>
+// U8 (implies the VEC4 item shape): the input is uint8 HWC (`src/testing.py:99-104` BEFORE ToTensor / Normalize): one
+// 12-byte load fetches the 4 pixels x RGB of an item, and every byte goes through a 256-entry table per channel that
+// holds ((u / 255) - mean) / std already rounded to the storage type - bit-identical to frmap_normalize_u8_hwc
+// followed by the fp32 path, without the 602 KB/face fp32 tensor ever existing (150 KB/face are read instead).
+// Tiles: the grid is persistent (two workgroups per CU).  Workgroups that share an XCD (blockIdx % 8) walk ONE
+// contiguous range of tiles together, so the input rows that vertically adjacent tiles both stage (19 rows per 12
+// new ones) are served by that XCD's L2 instead of being fetched again.  The NEXT tile's loads are issued before the
+// current tile's MFMA phase and land under it.
+// PF: issue the next tile's loads before the current tile's MFMA phase (costs NIT x 3 x 4 staging registers in the
+// fp32 path - the 256-register budget then spills ~15 - and NIT x 3 in the uint8 path).
+template <typename TT, bool POOL3, bool VEC4, bool U8, bool PF>
 __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams p) {
   constexpr int MI = POOL3 ? 7 : 6, NI = 4, KSTEPS = 7, KPAD = 224, WPITCH = (KPAD + 8) * 2;
   constexpr int PADL0 = POOL3 ? 5 : 3, NROWS = 2 * (MI - 1) + 7;
@@ -70,6 +83,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
   char* halo = smem;
   char* wl = smem + ((NROWS * WLH * 8 + 1023) & ~1023);
   char* scratch_all = wl + 64 * WPITCH;
+  typename TT::elem* lut = (typename TT::elem*)(scratch_all + 4 * 16 * PITCH);  // U8: [3][256] normalised values
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -77,8 +91,20 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
   const size_t HW = (size_t)p.Hi * p.Wi;
   const int plane_b = (int)(HW * 4);
   const int ntiles = p.N * p.rgroups * p.nhalves;
-  int tile = blockIdx.x;
-  if (tile >= ntiles) return;
+  // workgroups b, b + 8, b + 16 ... share an XCD: they walk the XCD's contiguous tile range side by side
+  // (grids smaller than 8 workgroups: as many ranges as workgroups)
+  const int nx = (int)gridDim.x < 8 ? (int)gridDim.x : 8;
+  const int xcd = blockIdx.x % nx, wg_in_xcd = blockIdx.x / nx;
+  const int wgs_in_xcd = ((int)gridDim.x - xcd + nx - 1) / nx;
+  const int t_lo = (int)(((long long)ntiles * xcd) / nx), t_hi = (int)(((long long)ntiles * (xcd + 1)) / nx);
+  int tile = t_lo + wg_in_xcd;
+  if (U8) {  // the table is needed by every workgroup that stages anything
+    for (int i = tid; i < 768; i += 256) {
+      const int c = i >> 8, u = i & 255;
+      lut[i] = TT::from_f32(((float)u / 255.0f - p.mean[c]) / p.std[c]);
+    }
+  }
+  if (tile >= t_hi) return;
 
   {  // weights: [64][232] image (same packing as conv_small_cin), resident for the whole kernel
     const u32x4_t* src = (const u32x4_t*)p.wpk;
@@ -93,20 +119,43 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
   const int j = lane >> 3, part = lane & 7;  // store item: pooled column j of the strip, 8-channel run `part`
   const f32x4_t s0 = *(const f32x4_t*)(p.shift + part * 8), s1 = *(const f32x4_t*)(p.shift + part * 8 + 4);
 
-  for (; tile < ntiles; tile += gridDim.x) {
-    const int half = tile % p.nhalves;
-    const int t2 = tile / p.nhalves;
-    const int n = __builtin_amdgcn_readfirstlane(t2 / p.rgroups);
-    const int rg = t2 - n * p.rgroups;
-    const int py0 = rg * 3, cr0 = POOL3 ? 2 * py0 - 1 : 2 * py0, ir0 = 2 * cr0 - 3;
-    const int strip = half * 4 + wave;
+  // ---- staging, split into issue (global loads into registers) and commit (pack + LDS writes) ----------------
+  // fp32: per-image buffer descriptor with 32-bit offsets, colour planes via the scalar offset; pixels outside
+  // the image get an out-of-range offset -> the bounds check returns 0.0 (zero padding)
+  float fs[(!VEC4 && !U8) ? NIT : 1][6];
+  u32x4_t fv[(VEC4 && !U8) ? NIT : 1][3];
+  u32x4_t fb[U8 ? NIT : 1];
+  unsigned okm = 0;  // U8: bit k = item k lies inside the image (padding must be 0 in NORMALISED space)
+  auto tile_geom = [&](int t, int& n, int& py0, int& half) {
+    half = t % p.nhalves;
+    const int t2 = t / p.nhalves;
+    n = __builtin_amdgcn_readfirstlane(t2 / p.rgroups);
+    py0 = (t2 - n * p.rgroups) * 3;
+  };
+  auto issue = [&](int t) {
+    int n, py0, half;
+    tile_geom(t, n, py0, half);
+    const int cr0 = POOL3 ? 2 * py0 - 1 : 2 * py0, ir0 = 2 * cr0 - 3;
     const int colbase = 2 * CSTEP * 4 * half;  // input-column origin of this half (4 strips x CSTEP conv columns x stride 2)
-    // ---- stage 19 input rows x 122 pixels straight from fp32 NCHW (all loads issued, then packed) --
-    if (!VEC4) {
-      // per-image buffer descriptor: 32-bit offsets, colour planes via the scalar offset, pixels
-      // outside the image get an out-of-range offset -> the bounds check returns 0.0 (zero padding)
+    if (U8) {
+      const int img_b = (int)(HW * 3);
+      auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x8 + (size_t)n * HW * 3), (short)0, img_b, 0x00020000);
+      okm = 0;
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const int item = tid + k * 256;
+        const bool iv = item < NITEMS;
+        const int r = (iv ? item : 0) / NGRP;
+        const int ix = ((iv ? item : 0) - r * NGRP) * 4 - (PADL - 1) + colbase;  // a multiple of 4: the group is all in or all out
+        const int iy = ir0 + r;
+        const bool ok = iv && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        const int o = ok ? (iy * p.Wi + ix) * 3 : 0x7FFFFFF0;
+        const auto v3 = __builtin_amdgcn_raw_buffer_load_b96(rsrc, o, 0, 0);
+        fb[k] = (u32x4_t){v3[0], v3[1], v3[2], 0u};
+        okm |= ok ? (1u << k) : 0u;
+      }
+    } else if (!VEC4) {
       auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)n * 3 * HW), (short)0, 3 * plane_b, 0x00020000);
-      float f[NIT][6];
 #pragma unroll
       for (int k = 0; k < NIT; ++k) {
         const int item = tid + k * 256;
@@ -120,20 +169,12 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
         const int o1 = (rowok && (unsigned)ix1 < (unsigned)p.Wi) ? (rowoff + ix1) * 4 : 0x7FFFFFF0;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          f[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, o0, c * plane_b, 0));
-          f[k][3 + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, o1, c * plane_b, 0));
+          fs[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, o0, c * plane_b, 0));
+          fs[k][3 + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, o1, c * plane_b, 0));
         }
       }
-#pragma unroll
-      for (int k = 0; k < NIT; ++k)
-        if (tid + k * 256 < NITEMS) {
-          const float q[8] = {f[k][0], f[k][1], f[k][2], 0.f, f[k][3], f[k][4], f[k][5], 0.f};
-          *(u32x4_t*)(halo + (tid + k * 256) * 16) = pack8<TT>(q);
-        }
-    }
-    if (VEC4) {
+    } else {
       auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)n * 3 * HW), (short)0, 3 * plane_b, 0x00020000);
-      u32x4_t f[NIT][3];
 #pragma unroll
       for (int k = 0; k < NIT; ++k) {
         const int item = tid + k * 256;
@@ -144,8 +185,42 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
         const bool ok = iv && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
         const int o = ok ? (iy * p.Wi + ix) * 4 : 0x7FFFFFF0;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) f[k][c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, c * plane_b, 0);
+        for (int c = 0; c < 3; ++c) fv[k][c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, c * plane_b, 0);
       }
+    }
+  };
+  auto commit = [&]() {
+    if (U8) {
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const int item = tid + k * 256;
+        if (item < NITEMS) {
+          const int r = item / NGRP, q = item - r * NGRP;
+          char* dst = halo + (r * WLH + 4 * q + 1) * 8;
+          const bool ok = (okm >> k) & 1u;
+          const unsigned w0 = fb[k][0], w1 = fb[k][1], w2 = fb[k][2];
+          // 12 bytes = 4 pixels x RGB: byte j of the item is channel j % 3 of pixel j / 3
+          const unsigned bytes[12] = {w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u, w0 >> 24,
+                                      w1 & 255u, (w1 >> 8) & 255u, (w1 >> 16) & 255u, w1 >> 24,
+                                      w2 & 255u, (w2 >> 8) & 255u, (w2 >> 16) & 255u, w2 >> 24};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            typename TT::elem px[4] = {lut[bytes[3 * e]], lut[256 + bytes[3 * e + 1]], lut[512 + bytes[3 * e + 2]], TT::from_f32(0.f)};
+            u32x2_t w;
+            __builtin_memcpy(&w, px, 8);
+            if (!ok) w = (u32x2_t){0u, 0u};
+            *(u32x2_t*)(dst + e * 8) = w;
+          }
+        }
+      }
+    } else if (!VEC4) {
+#pragma unroll
+      for (int k = 0; k < NIT; ++k)
+        if (tid + k * 256 < NITEMS) {
+          const float q[8] = {fs[k][0], fs[k][1], fs[k][2], 0.f, fs[k][3], fs[k][4], fs[k][5], 0.f};
+          *(u32x4_t*)(halo + (tid + k * 256) * 16) = pack8<TT>(q);
+        }
+    } else {
 #pragma unroll
       for (int k = 0; k < NIT; ++k) {
         const int item = tid + k * 256;
@@ -156,13 +231,25 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
           for (int e = 0; e < 4; ++e)
           {
             // (copy the lane first: __builtin_bit_cast applied directly to a vector-element lvalue reads element 0)
-            const unsigned r0 = f[k][0][e], g0 = f[k][1][e], b0 = f[k][2][e];
+            const unsigned r0 = fv[k][0][e], g0 = fv[k][1][e], b0 = fv[k][2][e];
             *(u32x2_t*)(dst + e * 8) = pack4<TT>(__uint_as_float(r0), __uint_as_float(g0), __uint_as_float(b0), 0.f);
           }
         }
       }
     }
+  };
+
+  if (U8) __syncthreads();  // the table is complete before the first commit reads it
+  if (PF) issue(tile);
+  for (; tile < t_hi; tile += wgs_in_xcd) {
+    int n, py0, half;
+    tile_geom(tile, n, py0, half);
+    const int cr0 = POOL3 ? 2 * py0 - 1 : 2 * py0;
+    const int strip = half * 4 + wave;
+    if (!PF) issue(tile);
+    commit();
     __syncthreads();
+    if (PF && tile + wgs_in_xcd < t_hi) issue(tile + wgs_in_xcd);  // the next tile's rows land under this tile's MFMA phase
 
     const bool active = strip < p.nstrips;
     if (active) {
@@ -232,13 +319,19 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
   }
 }
 
-static int stem_launch(const float* x_nchw, const void* w_packed_c3, const float* shift, void* out, int B, int Hi, int Wi,
+static int stem_launch(const float* x_nchw, const unsigned char* x_u8, const float* mean3, const float* std3,
+                       const void* w_packed_c3, const float* shift, void* out, int B, int Hi, int Wi,
                        int pool3, int dtype, void* stream, const char* who) {
-  FRMAP_REQUIRE(x_nchw && w_packed_c3 && shift && out, "%s: null pointer", who);
+  FRMAP_REQUIRE((x_nchw || x_u8) && w_packed_c3 && shift && out, "%s: null pointer", who);
   FRMAP_REQUIRE(dtype == FRMAP_BF16 || dtype == FRMAP_F16, "%s: bad dtype %d", who, dtype);
   FRMAP_REQUIRE(B > 0 && Hi >= 7 && Wi >= 7 && (long long)Hi * Wi * 12 < 0x7FFFFF00ll, "%s: bad input size", who);
   StemPoolParams p;
-  p.x = x_nchw; p.wpk = w_packed_c3; p.shift = shift; p.out = out;
+  p.x = x_nchw; p.x8 = x_u8; p.wpk = w_packed_c3; p.shift = shift; p.out = out;
+  for (int c = 0; c < 3; ++c) { p.mean[c] = mean3 ? mean3[c] : 0.f; p.std[c] = std3 ? std3[c] : 1.f; }
+  if (x_u8) {
+    FRMAP_REQUIRE(mean3 && std3 && std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, "%s: mean / non-zero std required", who);
+    FRMAP_REQUIRE(Wi % 4 == 0 && ((uintptr_t)x_u8 & 3) == 0, "%s: uint8 input needs W %% 4 == 0 and a 4-byte aligned tensor (W=%d)", who, Wi);
+  }
   p.N = B; p.Hi = Hi; p.Wi = Wi;
   p.Hc = (Hi + 6 - 7) / 2 + 1; p.Wc = (Wi + 6 - 7) / 2 + 1;
   if (pool3) { p.Hq = (p.Hc + 2 - 3) / 2 + 1; p.Wq = (p.Wc + 2 - 3) / 2 + 1; }
@@ -255,14 +348,14 @@ static int stem_launch(const float* x_nchw, const void* w_packed_c3, const float
   const long long nb = (long long)B * p.rgroups * p.nhalves;
   FRMAP_REQUIRE(nb < (1ll << 31), "%s: too many tiles", who);
   const int nrows = 2 * (mi - 1) + 7;
-  // 16-byte staging loads when rows are 16-byte aligned (W % 4 == 0, aligned base)
-  const bool vec4 = Wi % 4 == 0 && ((uintptr_t)x_nchw & 15) == 0;
+  // 16-byte staging loads when rows are 16-byte aligned (W % 4 == 0, aligned base); the uint8 path uses the same item shape
+  const bool vec4 = x_u8 ? true : (Wi % 4 == 0 && ((uintptr_t)x_nchw & 15) == 0);
   const int wlh = vec4 ? 4 * (pool3 ? 32 : 35) + 2 : p.Wl;  // must mirror the kernel's WLH
   const int hb = (nrows * wlh * 8 + 1023) & ~1023;
   p.halo_bytes = hb;
   const int wbytes = 64 * 232 * 2;
   const int scratch = 4 * 16 * (4 * 64 + 16);
-  const int lds = hb + wbytes + scratch;
+  const int lds = hb + wbytes + scratch + 3 * 256 * 2;  // + the uint8 normalisation table
   static int ncu = 0;
   if (!ncu) {
     int dev = 0;
@@ -274,11 +367,19 @@ static int stem_launch(const float* x_nchw, const void* w_packed_c3, const float
   const unsigned grid = (unsigned)(nb < 2ll * ncu ? nb : 2ll * ncu);
   hipStream_t st = (hipStream_t)stream;
   typedef void (*kern_t)(const StemPoolParams);
-  static const kern_t kerns[8] = {
-      stem_pool_kernel<BF16, false, false>, stem_pool_kernel<BF16, false, true>, stem_pool_kernel<BF16, true, false>,
-      stem_pool_kernel<BF16, true, true>,   stem_pool_kernel<F16, false, false>, stem_pool_kernel<F16, false, true>,
-      stem_pool_kernel<F16, true, false>,   stem_pool_kernel<F16, true, true>};
-  const int ai = (dtype == FRMAP_BF16 ? 0 : 4) + (pool3 ? 2 : 0) + (vec4 ? 1 : 0);
+  static const kern_t kerns[14] = {
+      stem_pool_kernel<BF16, false, false, false, false>, stem_pool_kernel<BF16, false, true, false, false>,
+      stem_pool_kernel<BF16, true, false, false, false>,  stem_pool_kernel<BF16, true, true, false, false>,
+      stem_pool_kernel<F16, false, false, false, false>,  stem_pool_kernel<F16, false, true, false, false>,
+      stem_pool_kernel<F16, true, false, false, false>,   stem_pool_kernel<F16, true, true, false, false>,
+      stem_pool_kernel<BF16, false, true, true, true>,    stem_pool_kernel<BF16, true, true, true, true>,
+      stem_pool_kernel<F16, false, true, true, true>,     stem_pool_kernel<F16, true, true, true, true>,
+      stem_pool_kernel<BF16, true, true, false, true>,    stem_pool_kernel<F16, true, true, false, true>};
+  static int pf32 = -1;  // A/B switch: FRMAP_STEM_PF=1 prefetches the next tile in the fp32 ResNet-stem kernel too
+  if (pf32 < 0) { const char* e = getenv("FRMAP_STEM_PF"); pf32 = e ? atoi(e) : 0; }
+  int ai = x_u8 ? 8 + (dtype == FRMAP_BF16 ? 0 : 2) + (pool3 ? 1 : 0)
+                : (dtype == FRMAP_BF16 ? 0 : 4) + (pool3 ? 2 : 0) + (vec4 ? 1 : 0);
+  if (!x_u8 && pf32 && pool3 && vec4) ai = dtype == FRMAP_BF16 ? 12 : 13;
   if (frmap_big_lds((const void*)kerns[ai], 160 * 1024)) return -2;
   hipLaunchKernelGGL(kerns[ai], dim3(grid), dim3(256), lds, st, p);
   FRMAP_LAUNCH_CHECK();
@@ -287,10 +388,20 @@ static int stem_launch(const float* x_nchw, const void* w_packed_c3, const float
 
 extern "C" int frmap_stem7x7_maxpool(const float* x_nchw, const void* w_packed_c3, const float* shift, void* out,
                                      int B, int Hi, int Wi, int dtype, void* stream) {
-  return stem_launch(x_nchw, w_packed_c3, shift, out, B, Hi, Wi, 1, dtype, stream, "stem7x7_maxpool");
+  FRMAP_REQUIRE(x_nchw, "stem7x7_maxpool: null input");
+  return stem_launch(x_nchw, nullptr, nullptr, nullptr, w_packed_c3, shift, out, B, Hi, Wi, 1, dtype, stream, "stem7x7_maxpool");
 }
 
 extern "C" int frmap_stem7x7_maxpool2(const float* x_nchw, const void* w_packed_c3, const float* shift, void* out,
                                       int B, int Hi, int Wi, int dtype, void* stream) {
-  return stem_launch(x_nchw, w_packed_c3, shift, out, B, Hi, Wi, 0, dtype, stream, "stem7x7_maxpool2");
+  FRMAP_REQUIRE(x_nchw, "stem7x7_maxpool2: null input");
+  return stem_launch(x_nchw, nullptr, nullptr, nullptr, w_packed_c3, shift, out, B, Hi, Wi, 0, dtype, stream, "stem7x7_maxpool2");
+}
+
+extern "C" int frmap_stem7x7_maxpool_u8(const unsigned char* x_u8_hwc, const float* mean3_host, const float* std3_host,
+                                        const void* w_packed_c3, const float* shift, void* out, int B, int Hi, int Wi,
+                                        int pool3, int dtype, void* stream) {
+  FRMAP_REQUIRE(x_u8_hwc, "stem7x7_maxpool_u8: null input");
+  return stem_launch(nullptr, x_u8_hwc, mean3_host, std3_host, w_packed_c3, shift, out, B, Hi, Wi, pool3 ? 1 : 0, dtype, stream,
+                     "stem7x7_maxpool_u8");
 }

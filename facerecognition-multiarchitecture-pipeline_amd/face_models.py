@@ -28,6 +28,7 @@ from . import ops
 MODEL_TYPES = ['baseline', 'cnn', 'siamese', 'attention', 'arcface', 'hybrid', 'ensemble']
 
 _DEFAULT_DTYPE = torch.bfloat16
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)   # `src/testing.py:102-103`
 
 
 def set_default_compute_dtype(dtype: torch.dtype) -> None:
@@ -103,6 +104,15 @@ class _HipModule(nn.Module):
         self._plan = None
         self._plan_sig = None
         self.compute_dtype = _DEFAULT_DTYPE
+        # uint8 HWC inputs (B×H×W×3 RGB, what `transforms.Resize` leaves, `src/testing.py:99-100`) are normalised on the
+        # device: ToTensor + Normalize(mean, std) of `src/testing.py:101-104` (ImageNet statistics by default)
+        self.input_mean, self.input_std = IMAGENET_MEAN, IMAGENET_STD
+
+    supports_u8_input = True
+
+    def set_input_normalization(self, mean, std):
+        self.input_mean, self.input_std = tuple(float(v) for v in mean), tuple(float(v) for v in std)
+        return self
 
     def set_compute_dtype(self, dtype: torch.dtype):
         ops.dt_code(dtype)
@@ -111,7 +121,7 @@ class _HipModule(nn.Module):
         return self
 
     def _signature(self):
-        sig = [self.compute_dtype]
+        sig = [self.compute_dtype, self.input_mean, self.input_std]
         for t in list(self.parameters()) + list(self.buffers()):
             sig.append((t.data_ptr(), t._version))
         return tuple(sig)
@@ -132,14 +142,25 @@ class _HipModule(nn.Module):
         raise NotImplementedError
 
     def _check_input(self, x: torch.Tensor) -> torch.Tensor:
-        if not isinstance(x, torch.Tensor) or x.dim() != 4 or x.shape[1] != 3:
-            raise ValueError(f"expected a B×3×H×W tensor, got {tuple(x.shape) if isinstance(x, torch.Tensor) else type(x)}")
+        """fp32 NCHW B×3×H×W (the reference's tensor) or uint8 HWC B×H×W×3 (the image bytes; normalised on the device)."""
+        u8 = isinstance(x, torch.Tensor) and x.dtype == torch.uint8
+        if not isinstance(x, torch.Tensor) or x.dim() != 4 or (x.shape[3] != 3 if u8 else x.shape[1] != 3):
+            raise ValueError(f"expected a B×3×H×W float tensor or a B×H×W×3 uint8 tensor, got "
+                             f"{tuple(x.shape) if isinstance(x, torch.Tensor) else type(x)}")
         if not x.is_cuda:
             raise RuntimeError("input is on the CPU; the HIP path needs GPU tensors (no CPU fallback)")
         if self.training:
             raise NotImplementedError(f"{type(self).__name__}: only eval-mode inference is implemented on the HIP path; "
                                       "call .eval() (training is out of scope, SURVEY.md §2.1)")
+        if u8:
+            return x
         return x.float() if x.dtype != torch.float32 else x
+
+    def _as_nhwc4(self, x: torch.Tensor) -> torch.Tensor:
+        """First-layer operand of the unfused paths: NHWC4 in the compute dtype from either input kind."""
+        if x.dtype == torch.uint8:
+            return ops.normalize_u8(x, self.input_mean, self.input_std, want_nchw=False, nhwc4_dtype=self.compute_dtype)[1]
+        return ops.pack_input(x, self.compute_dtype)
 
 
 # --------------------------------------------------------------------------------------------
@@ -190,8 +211,9 @@ class ResNet18(nn.Module):
 class _TrunkPlan:
     """Packed ResNet-18 trunk: stem conv → maxpool → 8 BasicBlocks (→ global average pool)."""
 
-    def __init__(self, rn: ResNet18, dtype: torch.dtype):
+    def __init__(self, rn: ResNet18, dtype: torch.dtype, mean=IMAGENET_MEAN, std=IMAGENET_STD):
         self.dtype = dtype
+        self.mean, self.std = mean, std
         self.stem = _PackedConv(rn.conv1, rn.bn1, dtype)
         self.blocks = []
         for li in range(1, 5):
@@ -203,8 +225,16 @@ class _TrunkPlan:
                 self.blocks.append((_PackedConv(blk.conv1, blk.bn1, dtype), c2, ds, fshift))
 
     def features(self, x: torch.Tensor) -> torch.Tensor:
-        """fp32 NCHW → NHWC B×7×7×512 (for 224² input) in the compute dtype."""
-        if ops.stem_pool_dims(x.shape[2], x.shape[3])[1] <= 56:
+        """fp32 NCHW (or uint8 HWC) → NHWC B×7×7×512 (for 224² input) in the compute dtype."""
+        if x.dtype == torch.uint8:
+            H, W = x.shape[1], x.shape[2]
+            if ops.stem_pool_dims(H, W)[1] <= 56 and W % 4 == 0:
+                # the fused stem reads the image bytes; ToTensor + Normalize happen while its rows are staged
+                x = ops.stem7x7_maxpool_u8(x, self.stem.wpk, self.stem.shift, self.mean, self.std, self.dtype)
+            else:
+                x4 = ops.normalize_u8(x, self.mean, self.std, want_nchw=False, nhwc4_dtype=self.dtype)[1]
+                x = ops.maxpool(self.stem(x4, relu=True), 3, 2, 1)
+        elif ops.stem_pool_dims(x.shape[2], x.shape[3])[1] <= 56:
             x = ops.stem7x7_maxpool(x, self.stem.wpk, self.stem.shift, self.dtype)   # fused stem, one kernel
         else:  # wider than the fused kernel's 8 column strips
             x = ops.maxpool(self.stem(ops.pack_input(x, self.dtype), relu=True), 3, 2, 1)
@@ -252,7 +282,7 @@ class BaselineNet(_HipModule):
     def get_embedding(self, x):
         x = self._check_input(x)
         p = self._get_plan()
-        x = ops.pack_input(x, self.compute_dtype)
+        x = self._as_nhwc4(x)
         x = ops.maxpool(p["c1"](x, relu=True), 2, 2, 0)
         x = ops.maxpool(p["c2"](x, relu=True), 2, 2, 0)
         x = ops.maxpool(p["c3"](x, relu=True), 2, 2, 0)
@@ -289,7 +319,7 @@ class ResNetTransfer(_HipModule):
             param.requires_grad = True
 
     def _build_plan(self, dtype):
-        return _TrunkPlan(self.resnet, dtype)
+        return _TrunkPlan(self.resnet, dtype, self.input_mean, self.input_std)
 
     def forward(self, x):
         x = self._check_input(x)
@@ -355,11 +385,17 @@ class SiameseNet(_HipModule):
         batch_size = x.size(0)
         self.debug_shapes["input"] = x.shape
         convs = p["convs"]
-        if ((x.shape[3] + 6 - 7) // 2 + 1) // 2 <= 64:   # fused conv.0-3: 7x7 conv + bias + BN + ReLU + MaxPool2d(2,2)
-            x = ops.stem7x7_maxpool(x, convs[0][0].wpk, convs[0][0].shift, self.compute_dtype, pool3=False)
+        u8 = x.dtype == torch.uint8
+        Wi = x.shape[2] if u8 else x.shape[3]
+        if ((Wi + 6 - 7) // 2 + 1) // 2 <= 64 and (not u8 or Wi % 4 == 0):   # fused conv.0-3: 7x7 conv + bias + BN + ReLU + MaxPool2d(2,2)
+            if u8:
+                x = ops.stem7x7_maxpool_u8(x, convs[0][0].wpk, convs[0][0].shift, self.input_mean, self.input_std,
+                                           self.compute_dtype, pool3=False)
+            else:
+                x = ops.stem7x7_maxpool(x, convs[0][0].wpk, convs[0][0].shift, self.compute_dtype, pool3=False)
             convs = convs[1:]
         else:
-            x = ops.pack_input(x, self.compute_dtype)
+            x = self._as_nhwc4(x)
         for conv, pool in convs:
             x = conv(x, relu=True)
             if pool:
@@ -471,7 +507,7 @@ class ArcFaceNet(_HipModule):
 
     def _build_plan(self, dtype):
         scale, shift = _bn_scale_shift(self.bn)
-        return {"trunk": _TrunkPlan(self.backbone, dtype), "bn_scale": scale, "bn_shift": shift}
+        return {"trunk": _TrunkPlan(self.backbone, dtype, self.input_mean, self.input_std), "bn_scale": scale, "bn_shift": shift}
 
     def _pre_norm(self, x):
         p = self._get_plan()
@@ -547,7 +583,7 @@ class HybridNet(_HipModule):
         tr = self.transformer
         f32 = lambda t: t.detach().float().contiguous()
         return {
-            "trunk": _TrunkPlan(self.cnn, dtype),
+            "trunk": _TrunkPlan(self.cnn, dtype, self.input_mean, self.input_std),
             "pos": f32(self.pos_encoding).view(self.seq_len, self.fdim),
             "n1": (f32(tr.norm1.weight), f32(tr.norm1.bias)), "n2": (f32(tr.norm2.weight), f32(tr.norm2.bias)),
             "nf": (f32(self.norm.weight), f32(self.norm.bias)),
@@ -630,7 +666,7 @@ class AttentionNet(_HipModule):
         a = self.attention
         w = torch.cat([a.query.weight, a.key.weight, a.value.weight], dim=0).detach().float()
         bias = torch.cat([a.query.bias, a.key.bias, a.value.bias], dim=0).detach().float()
-        return {"trunk": _TrunkPlan(self.backbone, dtype), "qkv": ops.pack_conv_weight(w.contiguous(), dtype),
+        return {"trunk": _TrunkPlan(self.backbone, dtype, self.input_mean, self.input_std), "qkv": ops.pack_conv_weight(w.contiguous(), dtype),
                 "qkv_bias": bias.contiguous(), "cq": a.query.weight.shape[0], "cqkv": w.shape[0],
                 "gamma": a.gamma.detach().float().contiguous(),
                 "sw": a.spatial_attention.conv.weight.detach().float().contiguous(),

@@ -134,6 +134,28 @@ def stem7x7_maxpool(x: torch.Tensor, wpk: torch.Tensor, shift: torch.Tensor, dty
     return out
 
 
+def stem7x7_maxpool_u8(x_u8: torch.Tensor, wpk: torch.Tensor, shift: torch.Tensor, mean, std, dtype: torch.dtype,
+                       pool3: bool = True) -> torch.Tensor:
+    """uint8 HWC B×H×W×3 (RGB) -> ToTensor + Normalize(mean, std) -> conv7x7 s2 + shift + ReLU -> maxpool -> NHWC
+    B×Hq×Wq×64 (``dtype``): the fused stem fed by the image bytes themselves (needs W % 4 == 0)."""
+    import ctypes as C
+    if not isinstance(x_u8, torch.Tensor) or x_u8.dtype != torch.uint8 or x_u8.dim() != 4 or x_u8.shape[3] != 3:
+        raise TypeError("stem7x7_maxpool_u8: expected a uint8 tensor of shape [B, H, W, 3]")
+    x_u8 = _dev(x_u8, "stem7x7_maxpool_u8.x")
+    B, H, W, _ = x_u8.shape
+    if pool3:
+        Hq, Wq = stem_pool_dims(H, W)
+    else:
+        Hq, Wq = ((H + 6 - 7) // 2 + 1) // 2, ((W + 6 - 7) // 2 + 1) // 2
+    out = torch.empty((B, Hq, Wq, 64), dtype=dtype, device=x_u8.device)
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    sd = (C.c_float * 3)(*[float(v) for v in std])
+    _lib.check(_lib.load().frmap_stem7x7_maxpool_u8(x_u8.data_ptr(), m, sd, _dev(wpk, "wpk", dtype).data_ptr(),
+                                                    _dev(shift, "shift", torch.float32).data_ptr(), out.data_ptr(),
+                                                    B, H, W, int(bool(pool3)), dt_code(dtype), _stream()), "stem7x7_maxpool_u8")
+    return out
+
+
 def conv_igemm(x: torch.Tensor, wpk: torch.Tensor, shift: torch.Tensor, Cout: int, k: int, stride: int, pad: int,
                relu, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``relu``: False/0 none, True/1 ReLU, 2 exact GELU."""
@@ -487,7 +509,7 @@ def arcmargin_eval(x: torch.Tensor, w: torch.Tensor, label: torch.Tensor, s: flo
 
 
 # every tensor-taking wrapper launches on its operands' device (see _on_operand_device)
-for _name in ("pack_input", "pack_conv_weight", "pack_conv_weight_c3", "conv_small_cin", "stem7x7_maxpool", "conv_igemm",
+for _name in ("pack_input", "pack_conv_weight", "pack_conv_weight_c3", "conv_small_cin", "stem7x7_maxpool", "stem7x7_maxpool_u8", "conv_igemm",
               "conv_igemm_ds", "linear_mfma", "maxpool", "avgpool_global", "avgpool_adaptive", "linear_f32", "l2_normalize",
               "cast_to_f32", "cast_from_f32", "add_pos_layernorm", "mha_tokens", "mean_layernorm", "cnn_attention",
               "normalize_u8", "softmax_argmax", "pairwise_distance", "match_top1", "gap_norm_match", "cosine_logits",

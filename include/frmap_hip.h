@@ -93,6 +93,16 @@ int frmap_stem7x7_maxpool(const float* x_nchw, const void* w_packed_c3, const fl
  * src/face_models.py:115-118); out = B×(Hc/2)×(Wc/2)×64. */
 int frmap_stem7x7_maxpool2(const float* x_nchw, const void* w_packed_c3, const float* shift, void* out,
                            int B, int Hi, int Wi, int dtype, void* stream);
+/* The same two fusions fed by the uint8 image itself: x_u8_hwc = B×Hi×Wi×3 RGB bytes (what
+ * transforms.Resize leaves, src/testing.py:99-100); ToTensor (u/255) + Normalize((x-mean)/std)
+ * (src/testing.py:101-104; mean/std: 3 floats each in HOST memory) are applied while the rows are
+ * staged, through a per-channel 256-entry table rounded to `dtype` exactly as
+ * frmap_normalize_u8_hwc + the fp32 entry points would — the 602 KB/face fp32 tensor never exists
+ * (SURVEY.md §8f row 1).  pool3 != 0: MaxPool2d(3,2,1) (ResNet stem); 0: MaxPool2d(2,2) (Siamese).
+ * Needs Wi % 4 == 0 and a 4-byte aligned tensor. */
+int frmap_stem7x7_maxpool_u8(const unsigned char* x_u8_hwc, const float* mean3_host, const float* std3_host,
+                             const void* w_packed_c3, const float* shift, void* out, int B, int Hi, int Wi,
+                             int pool3, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution, NHWC, MFMA 16x16x32 (bf16 / f16), fused epilogue

@@ -240,10 +240,13 @@ def test_evaluate_model_harness_on_synthetic_folders(tmp_path, calibrated_sd):
         ref = fo.evaluate_loop(mt, sd, cpu_batches())
         probs, rprobs = np.array(res["probabilities"]), ref["probabilities"]
         assert probs.shape == rprobs.shape == (45, 36) and res["targets"] == ref["targets"].tolist()
-        assert np.abs(probs - rprobs).max() < 3e-3
+        perr = float(np.abs(probs - rprobs).max())
+        assert perr < 3e-3
         top2 = np.sort(rprobs, axis=1)[:, -2:]
-        safe = (top2[:, 1] - top2[:, 0]) > 6e-3                                 # decisions fp16 cannot flip
-        assert (np.array(res["predictions"])[safe] == ref["predictions"][safe]).all() and safe.sum() >= 20
+        safe = (top2[:, 1] - top2[:, 0]) > 4 * perr                             # decisions the fp16 error cannot flip
+        print(f"evaluate_model {mt}: max |p - p_oracle| {perr:.2e}, {int(safe.sum())}/45 decisions outside the error band")
+        assert (np.array(res["predictions"])[safe] == ref["predictions"][safe]).all() and safe.sum() >= 10
+        assert (np.array(res["predictions"]) == ref["predictions"]).mean() > 0.8
         assert abs(res["test_loss"] - ref["test_loss"]) < 5e-3
         want = evaluate.classification_metrics(ref["targets"], np.array(res["predictions"]), rprobs)
         for k in ("accuracy", "precision", "recall", "f1"):
@@ -274,3 +277,43 @@ def test_evaluate_model_harness_on_synthetic_folders(tmp_path, calibrated_sd):
     assert (tmp_path / "s" / "siamese_network_results.json").exists()
     with pytest.raises(FileNotFoundError):
         evaluate.evaluate_model(m, "baseline", str(tmp_path / "nope_empty_dir_missing"))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_uint8_input_stem_is_bit_identical_to_normalize_then_fp32_path(dtype, calibrated_sd):
+    """§8(f)-1: the fused stem fed by the uint8 HWC image (`src/testing.py:99-104` applied while the rows are staged)
+    against ToTensor + Normalize as its own kernel followed by the fp32-NCHW stem: same rounding points, so the
+    pooled NHWC maps — and everything downstream — are bit-identical; and against the oracle on the normalised floats."""
+    from frmap_amd import evaluate
+    g = np.random.Generator(np.random.PCG64(4242))
+    sd = calibrated_sd("cnn")
+    m = _model("cnn", sd, dtype)
+    plan = m._get_plan()
+    for (B, H, W), pool3 in (((3, 224, 224), True), ((2, 160, 160), True), ((2, 112, 96), True), ((2, 224, 224), False), ((1, 64, 72), False)):
+        x8 = torch.from_numpy(g.integers(0, 256, (B, H, W, 3), dtype=np.uint8)).to(DEV)
+        xf = ops.normalize_u8(x8, evaluate.IMAGENET_MEAN, evaluate.IMAGENET_STD)[0]
+        a = ops.stem7x7_maxpool_u8(x8, plan.stem.wpk, plan.stem.shift, evaluate.IMAGENET_MEAN, evaluate.IMAGENET_STD, dtype, pool3=pool3)
+        b = ops.stem7x7_maxpool(xf, plan.stem.wpk, plan.stem.shift, dtype, pool3=pool3)
+        assert a.shape == b.shape and torch.equal(a, b), (B, H, W, pool3)
+    x8 = torch.from_numpy(g.integers(0, 256, (6, 224, 224, 3), dtype=np.uint8)).to(DEV)
+    xf = evaluate.preprocess(x8)
+    with torch.no_grad():
+        assert torch.equal(m.get_embedding(x8), m.get_embedding(xf))
+        assert torch.equal(m(x8), m(xf))
+        gal = frmap_amd.Gallery([f"id{i}" for i in range(36)], synth.unit_rows(3002, 36, 512), DEV)
+        i8, d8 = frmap_amd.embed_and_match(m, x8, gal, 1.5, normalize=True)
+        i_f, d_f = frmap_amd.embed_and_match(m, xf, gal, 1.5, normalize=True)
+        assert torch.equal(i8, i_f) and torch.equal(d8, d_f)
+        want = fo.cnn_embedding(sd, xf.cpu())
+        got = m.get_embedding(x8).float().cpu()
+        assert float((got - want).norm() / want.norm()) < (2.5e-2 if dtype == torch.bfloat16 else 4e-3)
+        # the other first layers: BaselineNet (NHWC4 straight from the bytes), SiameseNet (2x2-pool stem), odd widths (unfused)
+        for mt in ("baseline", "siamese"):
+            mm = _model(mt, calibrated_sd(mt), dtype)
+            assert torch.equal(mm.get_embedding(x8[:3]), mm.get_embedding(xf[:3])), mt
+        x8o = torch.from_numpy(g.integers(0, 256, (2, 225, 230, 3), dtype=np.uint8)).to(DEV)
+        assert torch.equal(m.get_embedding(x8o), m.get_embedding(evaluate.preprocess(x8o)))
+        m.set_input_normalization((0.5, 0.5, 0.5), (0.5, 0.5, 0.5))      # `src/app.py:41`
+        assert torch.equal(m.get_embedding(x8[:2]), m.get_embedding(evaluate.preprocess(x8[:2], evaluate.FACENET_MEAN, evaluate.FACENET_STD)))
+    with pytest.raises(ValueError):
+        m(torch.zeros((2, 3, 224, 224), dtype=torch.uint8, device=DEV))    # uint8 must be HWC
