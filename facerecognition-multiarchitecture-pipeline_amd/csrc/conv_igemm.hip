@@ -1170,6 +1170,12 @@ static int conv_igemm_impl(const void* in, const void* w_packed, const float* sh
       return 0;
     }
   }
+  // 3x3 stride 1 with Cin >= 128: the LDS-DMA ping-pong kernel (conv_pp.hip) when it takes the shape
+  if (stride == 1 && !ds.in && p.dbg == 0) {
+    const int rc = frmap_conv3x3_pp(in, w_packed, shift, residual, out, B, Hi, Wi, Cin, Cout, relu, dtype, st);
+    if (rc < 0) return rc;
+    if (rc == 1) return 0;
+  }
   // 3x3: pick the pixel tile so the halo fits; prefer 256 pixels
   int BM = 256;
   long long hb = (long long)halo_rows_bound(256, Ho, Wo, p.Hp, stride, 3) * p.Wp * 64;

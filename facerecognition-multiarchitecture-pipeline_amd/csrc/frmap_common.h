@@ -200,6 +200,9 @@ __device__ __forceinline__ int frmap_div(int n, FrmapDiv d) { return d.m ? (int)
 void frmap_set_error(const char* fmt, ...);
 // raise a kernel's dynamic-LDS limit on the CURRENT device (once per (kernel, device)); 0 or -2 with the error set
 int frmap_big_lds(const void* kern, int bytes);
+// second-generation 3x3 stride-1 kernel (conv_pp.hip): 1 = launched, 0 = shape not taken, < 0 = error
+int frmap_conv3x3_pp(const void* in, const void* w_packed, const float* shift, const void* residual, void* out, int B, int Hi,
+                     int Wi, int Cin, int Cout, int relu, int dtype, hipStream_t st);
 #define FRMAP_REQUIRE(cond, ...)        \
   do {                                  \
     if (!(cond)) {                      \

@@ -123,6 +123,11 @@ int frmap_conv_igemm(const void* in, const void* w_packed, const float* shift, c
                      void* out, int B, int Hi, int Wi, int Cin, int Cout, int K, int stride, int pad,
                      int relu, int dtype, void* stream);
 
+/* Tuning / test hook for the second-generation 3x3 stride-1 kernel behind frmap_conv_igemm (conv_pp.hip: 8-wave
+ * workgroups, LDS-DMA operands): enable (0 / 1, -1 = default), pixels per tile (<= 224, -1 = whole rows / images),
+ * channel tile (128 / 256, -1 = heuristic).  Process-wide; not needed for normal use. */
+int frmap_conv_pp_tuning(int enable, int tile_px, int bn);
+
 /* A 3x3 stride-1 pad-1 convolution with a ResNet projection shortcut folded in (BasicBlock.conv2 + bn2 + downsample
  * [conv1x1 stride s + bn] + add + ReLU of the first block of a stage, torchvision resnet.py via face_models.py:67):
  *   out = act( conv3x3(in, W) + conv1x1_stride_s(ds_in, W_ds) + shift ),   shift = shift_conv + shift_shortcut

@@ -406,3 +406,44 @@ def test_rejections_do_not_launch():
                        64, 3, 1, 1, True)            # Cin not a multiple of 32
     with pytest.raises(TypeError):
         ops.pack_input(torch.zeros(1, 3, 8, 8, device=DEV), torch.float32)
+
+
+def test_conv_pp_kernel_shapes_and_tilings():
+    """The LDS-DMA ping-pong 3x3 stride-1 kernel (conv_pp.hip) against fp32 torch: the ResNet layer-2/3/4 shapes, ragged
+    batches (tiles that cross image boundaries, a partial last tile), odd geometries, both channel tiles (128 / 256),
+    forced tile sizes that are not whole rows, residual / activation variants, one vs many 32-channel chunks; and the
+    first-generation kernels on the same inputs (the two generations must agree to rounding)."""
+    from frmap_amd import _lib
+    lib = _lib.load()
+    cases = [  # B, H, W, Cin, Cout, residual, act, tile_px, bn
+        (3, 14, 14, 256, 256, False, 1, -1, -1), (5, 14, 14, 256, 256, True, 1, -1, 256), (5, 14, 14, 256, 256, True, 1, -1, 128),
+        (9, 7, 7, 512, 512, True, 1, -1, -1), (9, 7, 7, 512, 512, False, 0, -1, 256), (2, 28, 28, 128, 128, True, 1, -1, -1),
+        (3, 28, 28, 128, 128, False, 1, 196, -1), (2, 13, 17, 128, 128, True, 2, -1, -1), (1, 56, 56, 128, 128, False, 1, -1, -1),
+        (2, 9, 40, 160, 384, True, 1, -1, -1), (4, 14, 14, 256, 256, False, 1, 100, -1), (7, 5, 3, 32, 128, True, 0, -1, -1),
+        (2, 3, 224, 64, 128, False, 1, -1, -1), (33, 7, 7, 128, 256, True, 1, 37, 256), (1, 1, 1, 1024, 128, False, 1, -1, -1),
+        (2, 56, 56, 64, 128, True, 1, -1, -1),
+    ]
+    try:
+        for ci, (B, H, W, Cin, Cout, res, act, px, bn) in enumerate(cases):
+            for dtype in DTYPES:
+                x = synth.randn(9100 + ci, (B, Cin, H, W), "x").to(dtype)
+                w = (synth.randn(9200 + ci, (Cout, Cin, 3, 3), "w") * math.sqrt(2.0 / (Cin * 9))).to(dtype)
+                shift = synth.randn(9300 + ci, (Cout,), "b") * 0.1
+                ref = F.conv2d(x.float(), w.float(), None, stride=1, padding=1) + shift.view(1, -1, 1, 1)
+                r = synth.randn(9400 + ci, tuple(ref.shape), "r").to(dtype) if res else None
+                if res:
+                    ref = ref + r.float()
+                ref = F.relu(ref) if act == 1 else (F.gelu(ref) if act == 2 else ref)
+                wpk = ops.pack_conv_weight(w.float().to(DEV), dtype)
+                xin, rin = _nhwc(x).to(DEV), (_nhwc(r).to(DEV) if res else None)
+                lib.frmap_conv_pp_tuning(1, px, bn)
+                y_pp = ops.conv_igemm(xin, wpk, shift.to(DEV), Cout, 3, 1, 1, act, rin)
+                lib.frmap_conv_pp_tuning(0, -1, -1)
+                y_g1 = ops.conv_igemm(xin, wpk, shift.to(DEV), Cout, 3, 1, 1, act, rin)
+                atol, rtol = _tol(dtype)
+                y = y_pp.float().cpu().permute(0, 3, 1, 2)
+                assert y.shape == ref.shape
+                assert torch.allclose(y, ref, atol=atol, rtol=rtol), (ci, dtype, float((y - ref).abs().max()))
+                assert torch.allclose(y_pp.float(), y_g1.float(), atol=atol, rtol=rtol), (ci, dtype, "generations differ")
+    finally:
+        lib.frmap_conv_pp_tuning(-1, -1, -1)

@@ -15,7 +15,11 @@ SHAPES = [  # name, H, Cin, Cout, k, stride, residual
 
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=256); ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--pp", type=int, default=-1, help="second-generation 3x3 s1 kernel: 1 force on (every Cin), 0 off, -1 default policy")
+    ap.add_argument("--tile-px", type=int, default=-1); ap.add_argument("--bn", type=int, default=-1)
     a = ap.parse_args()
+    from frmap_amd import _lib
+    _lib.load().frmap_conv_pp_tuning(a.pp, a.tile_px, a.bn)
     dev = "cuda"; dt = torch.bfloat16
     for name, H, Cin, Cout, k, s, res in SHAPES:
         pad = 1 if k == 3 else 0
