@@ -137,7 +137,22 @@ def _nbytes(t):
     return 0 if t is None else t.numel() * t.element_size()
 
 
-def _conv_kernel_name(dt, Cin, k, stride, H, W, ds):
+def _conv_kernel_name(dt, Cin, k, stride, H, W, ds, Cout=0, B=0):
+    if k == 3 and stride == 1 and not ds and Cin >= 128 and Cout % 128 == 0 and os.environ.get("FRMAP_CONV_PP", "1") != "0":
+        cap = 224 if Cout % 256 == 0 else 448
+        tile_px = (cap // (H * W)) * H * W if H * W <= cap else 0
+        if not tile_px:
+            rows = cap // W
+            for r in range(rows, 0, -1):
+                if r * 8 < rows * 7:
+                    break
+                if H % r == 0:
+                    rows = r
+                    break
+            tile_px = rows * W
+        tiles = -(-B * H * W // tile_px) * (Cout // (256 if Cout % 256 == 0 else 128))
+        if tiles >= int(os.environ.get("FRMAP_PP_MIN_TILES", "200")):
+            return f"conv3x3_pp_kernel<{dt}>"
     if ds:
         return f"conv3x3_fast_kernel<{dt}, true>"
     if k == 1:
@@ -172,7 +187,7 @@ def instrument(ops, torch, dt):
     def d_conv(out, x, wpk, shift, Cout, k, stride, pad, relu, residual=None):
         B, H, W, Cin = x.shape
         flop = 2.0 * out.shape[0] * out.shape[1] * out.shape[2] * Cout * Cin * k * k
-        return _conv_kernel_name(dt, Cin, k, stride, H, W, False), flop, _nbytes(x) + _nbytes(out) + _nbytes(wpk) + _nbytes(residual)
+        return _conv_kernel_name(dt, Cin, k, stride, H, W, False, Cout, B), flop, _nbytes(x) + _nbytes(out) + _nbytes(wpk) + _nbytes(residual)
 
     def d_conv_ds(out, x, wpk, shift, Cout, x_ds, wpk_ds, ds_stride, relu):
         B, H, W, Cin = x.shape

@@ -8,18 +8,20 @@
 //
 // Tile: tile_px consecutive flattened output pixels (n, oy, ox) x BN = NI*64 output channels.  tile_px <= 2*MI*16 is
 // chosen on the host as whole output rows (14x14 maps: one image = 196 pixels per workgroup, 256 faces = 256 CUs).
-//   wave w: group = w >> 2 (pixel half: MFMA column groups [group*MI, group*MI + MI)), wn = w & 3 (channels
-//   [wn*NI*16, +NI*16) of the tile): MI x NI MFMA 16x16x32 tiles per k-step, A = 16 output channels, B = 16 pixels.
+//   Every wave owns MI x 4 MFMA 16x16x32 tiles (MI*16 pixels x 64 channels; A = 16 output channels, B = 16 pixels).
+//   WM = 2: 2 pixel slices x 4 channel slices (BN = 256; group = wave >> 2 is the pixel slice);
+//   WM = 4: 4 pixel slices x 2 channel slices (BN = 128, for 128-channel layers; a group holds two pixel slices).
 // K loop: k-step = (32-channel chunk, tap).  LDS: two halo images (64 B per pixel, the XOR-swizzled layout of
-//   conv3x3_fast_kernel; a tap is an LDS offset) and a ring of three weight slabs (BN x 32 channels, pre-packed in
+//   conv3x3_fast_kernel; a tap is an LDS offset) and a ring of four weight slabs (BN x 32 channels, pre-packed in
 //   LDS-image order by frmap_pack_conv_weight, so a slab is a straight copy).
-// Pipeline per k-step and group:   LOAD(k): issue DMA {one piece of the NEXT chunk's halo, slab k+2}; ds_read the
-//   fragments of k-step k; s_waitcnt vmcnt(n) so that only THIS phase's DMA is still in flight (slab k+1 has landed);
-//   lgkmcnt(0); s_barrier; MFMA(k): MI*NI MFMAs; s_barrier.
+// Pipeline per k-step and group:   LOAD(k): ds_read the fragments of k-step k; issue DMA {one piece of the NEXT chunk's
+//   halo, slab k+2}; s_waitcnt vmcnt(n) so that only THIS phase's DMA is still in flight (slab k+1 has landed);
+//   s_barrier; MFMA(k): lgkmcnt(0), MI*NI MFMAs at raised priority; s_barrier.
 //   Group B runs one barrier behind group A, so A's MFMA(k) coincides with B's LOAD(k) and B's MFMA(k) with A's LOAD(k+1).
-//   Hazards: a slab is rewritten two phases after its last fragment read (ring of 3, prefetch distance 2), every read is
-//   retired (lgkmcnt(0)) before the barrier that precedes any DMA into its buffer, and DMA'd bytes are read only after
-//   the issuing waves' counted vmcnt AND a barrier every wave has passed.  DMA is issued from inline asm (hipcc would
+//   Hazards: a slab is rewritten by DMA issued two phases (four barriers) after the phase that read it (ring of 4,
+//   prefetch distance 2) and a halo buffer no earlier than tap 1 of the chunk after its last reader, so every fragment
+//   read is retired (the lgkmcnt(0) that opens the reader's MFMA segment) at least one barrier before any DMA into its
+//   buffer is issued; DMA'd bytes are read only after the issuing waves' counted vmcnt AND a barrier every wave has passed.  DMA is issued from inline asm (hipcc would
 //   otherwise drain vmcnt(0) ahead of every LDS read that may alias an outstanding LDS-DMA write), so every wait on it
 //   is hand-counted; the number of DMA instructions per phase is static (slabs / halo pieces past the end of the
 //   problem are fetched from valid dummy addresses into buffers nobody reads).
@@ -77,25 +79,39 @@ __device__ __forceinline__ void pp_static_for(std::integer_sequence<int, Is...>,
   (f(std::integral_constant<int, Is>{}), ...);
 }
 
-template <typename TT, int MI, int NI, int NHP>
+// KS = 1: both wave groups walk every 32-channel chunk (they split the tile's PIXELS).
+// KS = 2: in-workgroup split-K for layers with few output pixels (7x7 maps, small batches): the tile is MI*32 pixels x 128
+//         channels, each group covers ALL of it (2 pixel slices x 2 channel slices) but only every second chunk, with its
+//         own halo buffers and slab ring; at the end group B hands its accumulators to group A through LDS.  Twice the
+//         tiles of the KS = 1 layouts at the same per-wave MFMA shape and the same bytes staged per MFMA.
+template <typename TT, int MI, int WM, int NHP, int KS>
 __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
-  constexpr int TAPS = 9, BN = NI * 64, WB = BN * 64;      // slab bytes: BN channels x 32 channels x 2 B
-  constexpr int NWI = BN / 128;                              // slab DMA instructions per wave and k-step
-  constexpr int HB = NHP * 8 * 1024;                         // bytes of one halo image buffer
+  constexpr int NI = 4, WN = KS == 2 ? 2 : 8 / WM;
+  constexpr int TAPS = 9, BN = WN * 64, WB = BN * 64;      // slab bytes: BN channels x 32 channels x 2 B
+  constexpr int GW = 8 / KS;                                 // waves that share one set of LDS buffers
+  constexpr int NWI = (WB / 1024) / GW;                      // slab DMA instructions per wave and k-step (2, or 1 for BN = 128 / KS = 1)
+  constexpr int RING = 4;                                    // weight slabs in LDS (prefetch distance 2: a slab is rewritten
+                                                             // two full phases after the phase that last read it)
+  constexpr int HB = NHP * GW * 1024;                        // bytes of one halo image buffer
+  constexpr int GSZ = 2 * HB + RING * WB;                    // LDS of one buffer set: [halo 0][halo 1][slab 0 .. slab 3]
   using vec8 = typename TT::vec8;
   using elem = typename TT::elem;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // LDS map: [halo 0][halo 1][slab 0][slab 1][slab 2]; the epilogue's transpose scratch reuses it from 0
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2, wn = wave & 3;
+  const int grp = wave >> 2, q = wave & 3;
+  const int gw = KS == 2 ? q : wave;                                                     // index among the waves sharing the buffers
+  const int wn = (KS == 2 || WM == 4) ? (wave & 1) : q;                                  // channel slice (64 channels)
+  const int mslice = KS == 2 ? (q >> 1) : (WM == 2 ? grp : grp * 2 + (q >> 1));          // pixel slice (MI * 16 pixels)
+  const int gbase = KS == 2 ? grp * GSZ : 0;
   const int lr = lane & 15, g = lane >> 4;
 
   const int L = pp_xcd_remap(blockIdx.x, gridDim.x);
   const int mt = L / p.ntiles, nt = L - mt * p.ntiles;
   const int m0 = mt * p.tile_px, mend = min(m0 + p.tile_px, p.M);
-  const int nk = p.nchunks * TAPS;
+  const int nch = p.nchunks / KS;            // chunks this group walks (KS = 2: chunk = grp + 2 * ci)
+  const int nk = nch * TAPS;                 // its k-steps
 
   // ---- halo geometry of this tile (rows of the virtual padded row stack, as conv3x3_fast_kernel)
   const int n0 = frmap_div(m0, p.dHoWo), oy0 = frmap_div(m0 - n0 * p.HoWo, p.dWo);
@@ -104,11 +120,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
   const int nitems = nrows * p.Wp * 4;  // 16-byte items of one 32-channel halo image
 
   // ---- per-lane DMA sources
-  // halo piece j of this wave = piece (wave + 8j) of the image: lane -> pixel (piece*16 + lane/4), physical slot lane%4
+  // halo piece j of this wave = piece (gw + GW*j) of the image: lane -> pixel (piece*16 + lane/4), physical slot lane%4
   const char* hsrc[NHP];
 #pragma unroll
   for (int j = 0; j < NHP; ++j) {
-    const int item = ((wave + 8 * j) << 6) + lane;
+    const int item = ((gw + GW * j) << 6) + lane;
     const int px = item >> 2, ps = item & 3;
     const int cg = ps ^ (((px >> 2) & 1) << 1);  // logical 8-channel group stored at this physical slot (the read-side swizzle)
     const int r = (int)fast_div((uint32_t)px, p.magic_Wp);
@@ -120,45 +136,46 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
     hsrc[j] = ok ? (const char*)p.in + ((((size_t)n * p.Hi + iy) * p.Wi + ix) * p.Cin + cg * 8) * sizeof(elem)
                  : (const char*)g_pp_zero + cg * 16;   // padding pixels are DMA'd from 4 KB of zeros
   }
-  // slab pieces of this wave: BN = 256: instructions 2*wave, 2*wave + 1 of the 16 (block wave/2, 1-KB parts 2*(wave&1), +1);
-  //                           BN = 128: instruction wave of the 8 (block wave/4, part wave%4)
-  const int wblk = NWI == 2 ? (wave >> 1) : (wave >> 2);
-  const int wpart = NWI == 2 ? ((wave & 1) << 1) : (wave & 3);
+  // slab pieces of this wave: the WB/1024 instructions of a k-step are dealt over the GW waves (instruction i = 4-KB block
+  // i/4, 1-KB part i%4): NWI = 2: instructions 2*gw, 2*gw + 1; NWI = 1: instruction gw
+  const int wblk = NWI == 2 ? (gw >> 1) : (gw >> 2);
+  const int wpart = NWI == 2 ? ((gw & 1) << 1) : (gw & 3);
   const char* wsrc = (const char*)p.wpk + ((size_t)(nt * (BN / 64) + wblk) * p.nchunks * TAPS) * 4096 + wpart * 1024 + lane * 16;
-  const unsigned wdst = lds0 + 2 * HB + wblk * 4096 + wpart * 1024;  // + slot * WB
-  const unsigned hdst = lds0 + wave * 1024;                            // + buffer * HB + j * 8192
+  const unsigned wdst = lds0 + gbase + 2 * HB + wblk * 4096 + wpart * 1024;  // + slot * WB
+  const unsigned hdst = lds0 + gbase + gw * 1024;                              // + buffer * HB + j * GW * 1024
 
-  auto issue_slab = [&](int k, int slot) {  // slab of k-step k into ring slot k % 3 (past the end: a dummy copy nobody reads)
-    const int kc = k < nk ? k : nk - 1;
-    const char* s = wsrc + (size_t)kc * 4096;
+  // group-local k-step kk = (chunk counter ci, tap t) -> the layer's k-step (chunk * 9 + t)
+  auto issue_slab = [&](int ci, int t, int slot) {  // (past the end: a dummy copy of the last slab into a slot nobody reads)
+    const int cc = ci < nch ? ci : nch - 1;
+    const int chunk = KS == 2 ? grp + 2 * cc : cc;
+    const char* s = wsrc + (size_t)(chunk * TAPS + (ci < nch ? t : TAPS - 1)) * 4096;
     const unsigned d = wdst + (unsigned)slot * WB;
     pp_dma16(s, d);
     if (NWI == 2) pp_dma16(s + 1024, d + 1024);
   };
-  auto issue_halo = [&](int chunk, int j) {  // piece j of chunk `chunk` (past the last chunk: zeros into the idle buffer)
-    const char* s = chunk < p.nchunks ? hsrc[j] + (size_t)chunk * 64 : (const char*)g_pp_zero;
-    pp_dma16(s, hdst + (unsigned)(chunk & 1) * HB + j * 8192);
+  auto issue_halo = [&](int ci, int j) {  // piece j of the group's chunk ci (past the last chunk: zeros into the idle buffer)
+    const int chunk = KS == 2 ? grp + 2 * ci : ci;
+    const char* s = ci < nch ? hsrc[j] + (size_t)chunk * 64 : (const char*)g_pp_zero;
+    pp_dma16(s, hdst + (unsigned)(ci & 1) * HB + j * (GW * 1024));
   };
 
-  // ---- prologue: halo image of chunk 0, slabs 0 and 1
+  // ---- prologue: halo image of the first chunk, slabs 0 and 1
 #pragma unroll
   for (int j = 0; j < NHP; ++j) issue_halo(0, j);
-  issue_slab(0, 0);
-  issue_slab(1, 1);
+  issue_slab(0, 0, 0);
+  issue_slab(0, 1, 1);
 
   // fragment addressing
   int A[MI];  // (pixel index in the halo image) * 64 + k-group * 16, before the tap offset and the swizzle
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
-    const int m = min(m0 + (grp * MI + mi) * 16 + lr, mend - 1);
+    const int m = min(m0 + (mslice * MI + mi) * 16 + lr, mend - 1);
     const int n = frmap_div(m, p.dHoWo), rem = m - n * p.HoWo, oy = frmap_div(rem, p.dWo), ox = rem - oy * p.Wi;
     A[mi] = ((((n - n0) * p.Hp + oy - oy0) * p.Wp + ox) << 6) | (g << 4);
   }
   const int woff = (lr << 6) + ((g ^ (((lr >> 2) & 1) << 1)) << 4);
-  // this wave's 16*NI output channels inside the slab: BN = 256: block wn; BN = 128: block wn/2, second half for odd wn
-  const int wfo = NI == 4 ? wn * 4096 : (wn >> 1) * 4096 + (wn & 1) * 2048;
-  const char* halo = smem;
-  const char* slabs = smem + 2 * HB + wfo + woff;
+  const char* halo = smem + gbase;
+  const char* slabs = smem + gbase + 2 * HB + wn * 4096 + woff;  // this wave's 64 output channels = 4-KB block wn of a slab
 
   f32x4_t acc[MI][NI];
 #pragma unroll
@@ -170,17 +187,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
   pp_barrier();
   if (grp == 1) pp_barrier();  // group B runs one barrier behind group A from here on
 
-  for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-    const char* hb = halo + (chunk & 1) * HB;
+  for (int ci = 0; ci < nch; ++ci) {
+    const char* hb = halo + (ci & 1) * HB;
     pp_static_for(std::make_integer_sequence<int, TAPS>{}, [&](auto tc) {
       constexpr int t = decltype(tc)::value;
-      const int k = chunk * TAPS + t;
-      // ---------------- LOAD(k)
-      if (t < NHP) issue_halo(chunk + 1, t);
-      issue_slab(k + 2, (t + 2) % 3);   // (9 taps per chunk: k % 3 == t % 3)
+      const int k = ci * TAPS + t;
+      // ---------------- LOAD(k): fragment reads first (their latency runs under the DMA issue and the barrier wait)
       vec8 wf[NI], pf[MI];
       {
-        const char* sl = slabs + (t % 3) * WB;
+        const char* sl = slabs + (k & (RING - 1)) * WB;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) wf[ni] = *(const vec8*)(sl + ni * 1024);
         const int toff = ((t / 3) * p.Wp + (t % 3)) << 6;
@@ -190,10 +205,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
           pf[mi] = *(const vec8*)(hb + (at ^ ((at >> 3) & 32)));
         }
       }
-      pp_wait_vm<NWI + (t < NHP ? 1 : 0)>();  // everything older than this phase's DMA has landed (slab k+1; next halo by t = 8)
-      pp_wait_lgkm0();                         // this phase's fragment reads are retired before the barrier
+      constexpr bool HP = t >= 1 && t <= NHP;   // (no halo DMA at tap 0: the other group may still be reading that buffer's last tap)
+      if (HP) issue_halo(ci + 1, t - 1);
+      issue_slab(t + 2 < TAPS ? ci : ci + 1, (t + 2) % TAPS, (k + 2) & (RING - 1));
+      pp_wait_vm<NWI + (HP ? 1 : 0)>();  // everything older than this phase's DMA has landed (slab k+1; next halo by t = 8)
       pp_barrier();
       // ---------------- MFMA(k)
+      pp_wait_lgkm0();
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -202,12 +221,35 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
     });
   }
   if (grp == 0) pp_barrier();  // balance group B's extra start barrier
-  pp_wait_vm<0>();             // the dummy DMA of the last two phases must not land in the epilogue's scratch
+  pp_wait_vm<0>();             // the dummy DMA of the last two phases must not land in the buffers reused below
   pp_barrier();
 
+  if (KS == 2) {
+    // group B's partial sums -> LDS -> group A (wave q of B holds exactly the tiles wave q of A holds)
+    char* xch = smem + (size_t)q * (MI * NI * 1024) + lane * 16;
+    if (grp == 1) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) *(f32x4_t*)(xch + (mi * NI + ni) * 1024) = acc[mi][ni];
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const f32x4_t o = *(const f32x4_t*)(xch + (mi * NI + ni) * 1024);
+          acc[mi][ni][0] += o[0]; acc[mi][ni][1] += o[1]; acc[mi][ni][2] += o[2]; acc[mi][ni][3] += o[3];
+        }
+    }
+    __syncthreads();         // the exchange area is consumed: group A's transpose scratch may overwrite it
+    if (grp == 1) return;    // (no barrier below: conv_epilogue works on per-wave scratch)
+  }
+
   // ---- epilogue: + shift (+ residual) (activation) -> NHWC, whole-line 16-byte stores via a per-wave LDS transpose
-  conv_epilogue<TT, MI, NI>(acc, smem + wave * (16 * (NI * 64 + 16)), m0 + grp * (MI * 16), mend, p.Cout,
-                            nt * BN + wn * (NI * 16), p.shift, (const elem*)p.res, (elem*)p.out, p.relu, lane);
+  conv_epilogue<TT, MI, NI>(acc, smem + (KS == 2 ? q : wave) * (16 * (NI * 64 + 16)), m0 + mslice * (MI * 16), mend, p.Cout,
+                            nt * BN + wn * 64, p.shift, (const elem*)p.res, (elem*)p.out, p.relu, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -218,22 +260,26 @@ static int pp_env(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 // run-time overrides (frmap_conv_pp_tuning): -1 = not set (environment / heuristic decides)
-static int g_pp_on = -1, g_pp_px = -1, g_pp_bn = -1;
+static int g_pp_on = -1, g_pp_px = -1, g_pp_bn = -1, g_pp_ks = -1;
 
 extern "C" int frmap_conv_pp_tuning(int enable, int tile_px, int bn) {
   g_pp_on = enable;
   g_pp_px = tile_px;
-  g_pp_bn = bn;
+  g_pp_bn = bn == 1282 ? 128 : bn;   // (1282: the 128-channel tile with the two wave groups splitting K)
+  g_pp_ks = bn == 1282 ? 2 : (bn == 128 || bn == 256 ? 1 : -1);
   return 0;
 }
 
-template <typename TT, int MI, int NI, int NHP>
+template <typename TT, int MI, int WM, int NHP, int KS>
 static int pp_launch(const PPParams& p, hipStream_t st) {
-  auto kern = conv3x3_pp_kernel<TT, MI, NI, NHP>;
+  auto kern = conv3x3_pp_kernel<TT, MI, WM, NHP, KS>;
   if (frmap_big_lds((const void*)kern, 160 * 1024)) return -2;
-  int lds = 2 * NHP * 8192 + 3 * NI * 64 * 64;
-  const int scratch = 8 * 16 * (NI * 64 + 16);
+  const int wb = (KS == 2 ? 2 : 8 / WM) * 64 * 64;
+  int lds = KS * (2 * NHP * (8 / KS) * 1024 + 4 * wb);
+  const int scratch = 8 * 16 * (4 * 64 + 16);
+  const int xch = KS == 2 ? 4 * MI * 4 * 1024 : 0;
   if (lds < scratch) lds = scratch;
+  if (lds < xch) lds = xch;
   hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles), dim3(512), lds, st, p);
   FRMAP_LAUNCH_CHECK();
   return 0;
@@ -243,23 +289,19 @@ static int pp_launch(const PPParams& p, hipStream_t st) {
 // first-generation kernels), negative on a launch error.
 int frmap_conv3x3_pp(const void* in, const void* w_packed, const float* shift, const void* residual, void* out, int B, int Hi,
                      int Wi, int Cin, int Cout, int relu, int dtype, hipStream_t st) {
-  static int on = -1, force_px = 0, force_bn = 0, min_cin = 128;
+  static int on = -1, force_px = 0, force_bn = 0, min_cin = 128, min_tiles = 200;
   if (on < 0) {
+    min_tiles = pp_env("FRMAP_PP_MIN_TILES", 200);  // fewer tiles than this leave CUs idle: the first-generation kernels' smaller tiles win
     min_cin = pp_env("FRMAP_PP_MIN_CIN", 128);   // Cin = 64 layers keep the weights-resident wave kernel by default
     on = pp_env("FRMAP_CONV_PP", 1);
     force_px = pp_env("FRMAP_PP_TILE_PX", 0);
     force_bn = pp_env("FRMAP_PP_BN", 0);
   }
-  constexpr int MI = 7, BM = 2 * MI * 16;
+  constexpr int MI = 7;
   if (g_pp_on >= 0 ? !g_pp_on : (!on || Cin < min_cin)) return 0;   // (forced on by the hook: every Cin % 32 == 0)
-  if (Cin % 32 || Cin > 1024 || Cout % 128 || Wi > BM) return 0;
+  if (Cin % 32 || Cin > 1024 || Cout % 128) return 0;
   const long long Mll = (long long)B * Hi * Wi;
   if (Mll >= (1ll << 31) || (long long)B * Hi * Wi * Cin * 2 >= (1ll << 46)) return 0;
-  int rows = BM / Wi;
-  int tile_px = rows * Wi;
-  if (Hi * Wi <= BM && BM / (Hi * Wi) >= 1) tile_px = (BM / (Hi * Wi)) * Hi * Wi;  // whole images when they fit (7x7: 4, 14x14: 1)
-  if (force_px > 0 && force_px <= BM) tile_px = force_px;
-  if (g_pp_px > 0 && g_pp_px <= BM) tile_px = g_pp_px;
   PPParams p;
   p.in = in; p.wpk = w_packed; p.shift = shift; p.res = residual; p.out = out;
   p.N = B; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
@@ -267,24 +309,53 @@ int frmap_conv3x3_pp(const void* in, const void* w_packed, const float* shift, c
   p.magic_Wp = frmap_magic((uint32_t)p.Wp); p.magic_Hp = frmap_magic((uint32_t)p.Hp);
   p.dHoWo = frmap_div_make((uint32_t)p.HoWo); p.dWo = frmap_div_make((uint32_t)Wi);
   p.nchunks = Cin / 32;
-  p.tile_px = tile_px;
-  p.mtiles = (p.M + tile_px - 1) / tile_px;
-  // halo rows a tile can touch: its output rows + 2, plus the padded-row jump at every image boundary it crosses
-  const int orows = (tile_px + Wi - 2) / Wi + 1;                       // output rows touched (unaligned start)
-  const int cross = (tile_px + Hi * Wi - 2) / (Hi * Wi);               // image boundaries crossed
-  const long long hrows = orows + 2 + 2ll * cross;
-  const long long hbytes = hrows * p.Wp * 64;
-  int nhp = (int)((hbytes + 8191) / 8192);
-  if (nhp > 5 || hbytes / 64 >= 65536) return 0;
-  // channel tile: 256 when that still gives every CU a tile, else 128
-  int bn = (Cout % 256 == 0 && (long long)p.mtiles * (Cout / 256) >= 200) ? 256 : 128;
-  if (force_bn == 128 || force_bn == 256) bn = (force_bn == 256 && Cout % 256) ? 128 : force_bn;
-  if (g_pp_bn == 128 || g_pp_bn == 256) bn = (g_pp_bn == 256 && Cout % 256) ? 128 : g_pp_bn;
-  p.ntiles = Cout / bn;
+  // A layout = (pixels a tile can hold, channel tile, split-K groups).  Pixels per tile: whole images when they fit
+  // (7x7: 4 per 224, 14x14: 1), else whole rows - a divisor of the image height when one is within 1/8 of the capacity
+  // (28 rows, capacity 16 rows: 14), so tiles do not straddle images.  Returns the halo pieces (KB / waves) needed, 0 = no fit.
+  auto plan = [&](int cap, int bn, int ks, int& tile_px, int& mtiles, int& ntiles) -> int {
+    if (Wi > cap || Cout % bn || (ks == 2 && (Cin / 32) % 2)) return 0;
+    if (Hi * Wi <= cap) tile_px = (cap / (Hi * Wi)) * Hi * Wi;
+    else {
+      int rows = cap / Wi;
+      for (int r = rows; r * 8 >= rows * 7 && r >= 1; --r)
+        if (Hi % r == 0) { rows = r; break; }
+      tile_px = rows * Wi;
+    }
+    if (force_px > 0 && force_px <= cap) tile_px = force_px;
+    if (g_pp_px > 0 && g_pp_px <= cap) tile_px = g_pp_px;
+    mtiles = (int)((Mll + tile_px - 1) / tile_px);
+    ntiles = Cout / bn;
+    // halo rows a tile can touch: its output rows + 2, plus the padded-row jump at every image boundary it crosses
+    const int orows = (tile_px + Wi - 2) / Wi + 1;            // output rows touched (unaligned start)
+    const int cross = (tile_px + Hi * Wi - 2) / (Hi * Wi);    // image boundaries crossed
+    const long long hbytes = (long long)(orows + 2 + 2ll * cross) * p.Wp * 64;
+    if (hbytes / 64 >= 65536) return 0;
+    const int per = (8 / ks) * 1024;                           // bytes one "piece per wave" adds to the image
+    const int nhp = (int)((hbytes + per - 1) / per);
+    return nhp <= (ks == 2 ? 6 : 5) ? nhp : 0;
+  };
+  // candidates: 224 px x 256 ch; 448 px x 128 ch; split-K 224 px x 128 ch (twice the tiles of either)
+  int bn_pref = Cout % 256 == 0 ? 256 : 128;
+  if (force_bn == 128 || force_bn == 256) bn_pref = (force_bn == 256 && Cout % 256) ? 128 : force_bn;
+  if (g_pp_bn == 128 || g_pp_bn == 256) bn_pref = (g_pp_bn == 256 && Cout % 256) ? 128 : g_pp_bn;
+  int tpx = 0, mtl = 0, ntl = 0, ks = 1, bn = bn_pref;
+  int nhp = plan(bn == 256 ? 2 * MI * 16 : 4 * MI * 16, bn, 1, tpx, mtl, ntl);
+  const bool want_ks2 = g_pp_ks == 2 || (g_pp_ks < 0 && (!nhp || (long long)mtl * ntl < min_tiles));
+  if (want_ks2 && g_pp_ks != 1) {
+    int t2 = 0, m2 = 0, n2 = 0;
+    const int nhp2 = plan(2 * MI * 16, 128, 2, t2, m2, n2);
+    if (nhp2 && (g_pp_ks == 2 || !nhp || (long long)m2 * n2 > (long long)mtl * ntl)) {
+      nhp = nhp2; tpx = t2; mtl = m2; ntl = n2; ks = 2; bn = 128;
+    }
+  }
+  if (!nhp) return 0;
+  p.tile_px = tpx; p.mtiles = mtl; p.ntiles = ntl;
+  if (g_pp_on < 0 && (long long)mtl * ntl < min_tiles / 2) return 0;   // too few tiles even with split-K: the smaller first-generation tiles win
   int rc;
-#define PP_GO(TT)                                                                                  \
-  (bn == 256 ? (nhp <= 3 ? pp_launch<TT, MI, 4, 3>(p, st) : pp_launch<TT, MI, 4, 5>(p, st))        \
-             : (nhp <= 3 ? pp_launch<TT, MI, 2, 3>(p, st) : pp_launch<TT, MI, 2, 5>(p, st)))
+#define PP_GO(TT)                                                                                               \
+  (ks == 2 ? (nhp <= 4 ? pp_launch<TT, MI, 2, 4, 2>(p, st) : pp_launch<TT, MI, 2, 6, 2>(p, st))                  \
+   : bn == 256 ? (nhp <= 3 ? pp_launch<TT, MI, 2, 3, 1>(p, st) : pp_launch<TT, MI, 2, 5, 1>(p, st))              \
+               : (nhp <= 3 ? pp_launch<TT, MI, 4, 3, 1>(p, st) : pp_launch<TT, MI, 4, 5, 1>(p, st)))
   rc = dtype == FRMAP_BF16 ? PP_GO(BF16) : PP_GO(F16);
 #undef PP_GO
   return rc ? rc : 1;

@@ -125,7 +125,8 @@ int frmap_conv_igemm(const void* in, const void* w_packed, const float* shift, c
 
 /* Tuning / test hook for the second-generation 3x3 stride-1 kernel behind frmap_conv_igemm (conv_pp.hip: 8-wave
  * workgroups, LDS-DMA operands): enable (0 / 1, -1 = default), pixels per tile (<= 224, -1 = whole rows / images),
- * channel tile (128 / 256, -1 = heuristic).  Process-wide; not needed for normal use. */
+ * channel tile (128 / 256; 1282 = 128 channels with the wave groups splitting K; -1 = heuristic).  Process-wide; not
+ * needed for normal use. */
 int frmap_conv_pp_tuning(int enable, int tile_px, int bn);
 
 /* A 3x3 stride-1 pad-1 convolution with a ResNet projection shortcut folded in (BasicBlock.conv2 + bn2 + downsample

@@ -422,6 +422,10 @@ def test_conv_pp_kernel_shapes_and_tilings():
         (2, 9, 40, 160, 384, True, 1, -1, -1), (4, 14, 14, 256, 256, False, 1, 100, -1), (7, 5, 3, 32, 128, True, 0, -1, -1),
         (2, 3, 224, 64, 128, False, 1, -1, -1), (33, 7, 7, 128, 256, True, 1, 37, 256), (1, 1, 1, 1024, 128, False, 1, -1, -1),
         (2, 56, 56, 64, 128, True, 1, -1, -1),
+        # bn = 1282: 128-channel tiles with the two wave groups splitting K (accumulators merged through LDS)
+        (9, 7, 7, 512, 512, True, 1, -1, 1282), (5, 14, 14, 256, 256, False, 1, -1, 1282), (2, 28, 28, 128, 128, True, 2, -1, 1282),
+        (3, 13, 17, 128, 256, True, 0, -1, 1282), (33, 7, 7, 128, 256, True, 1, 37, 1282), (2, 20, 12, 64, 128, False, 1, -1, 1282),
+        (2, 9, 40, 160, 384, True, 1, -1, 1282),   # odd chunk count: split-K not applicable, falls back to the pixel split
     ]
     try:
         for ci, (B, H, W, Cin, Cout, res, act, px, bn) in enumerate(cases):

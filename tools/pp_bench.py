@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the plain 3x3 stride-1 layer shapes on the second-generation kernel (conv_pp.hip)."""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from frmap_amd import ops, _lib
+
+def main():
+    ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=256); ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--pp", type=int, default=1); ap.add_argument("--tile-px", type=int, default=-1); ap.add_argument("--bn", type=int, default=-1)
+    ap.add_argument("--relu-data", type=int, default=1, help="1: non-negative half-sparse activations (post-ReLU statistics), 0: N(0,1)")
+    ap.add_argument("--res", type=int, default=0); ap.add_argument("--variants", default="0,-1,256,128,1282")
+    a = ap.parse_args()
+    lib = _lib.load()
+    dev, dt = "cuda", torch.bfloat16
+    variants = [int(v) for v in a.variants.split(",")]   # channel-tile settings to compare: -1 heuristic, 128, 256, 1282 (split-K), 0 = first generation
+    for name, H, C in (("l2 28x28 128", 28, 128), ("l3 14x14 256", 14, 256), ("l4 7x7 512", 7, 512)):
+        x = torch.randn(a.batch, H, H, C, device=dev)
+        if a.relu_data: x = torch.relu(x)
+        x = x.to(dt)
+        w = ops.pack_conv_weight(torch.randn(C, C, 3, 3, device=dev) * (2.0 / (C * 9)) ** 0.5, dt)
+        sh = torch.zeros(C, device=dev)
+        r = torch.relu(torch.randn(a.batch, H, H, C, device=dev)).to(dt) if a.res else None
+        fl = 2.0 * a.batch * H * H * C * C * 9
+        res = {v: [] for v in variants}
+        for rnd in range(4):           # interleaved rounds in one process (variants compared on the same device / clocks)
+            for v in variants:
+                lib.frmap_conv_pp_tuning(a.pp if v != 0 else 0, a.tile_px, v)
+                for _ in range(3): ops.conv_igemm(x, w, sh, C, 3, 1, 1, True, r)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.reps): ops.conv_igemm(x, w, sh, C, 3, 1, 1, True, r)
+                e1.record(); torch.cuda.synchronize()
+                res[v].append(e0.elapsed_time(e1) / a.reps * 1e3)
+        print(f"{name:16s} " + "  ".join(f"bn{v}: {min(t):6.1f} us ({fl / min(t) / 1e6:5.0f} TF)" for v, t in res.items()), flush=True)
+
+if __name__ == "__main__":
+    main()
