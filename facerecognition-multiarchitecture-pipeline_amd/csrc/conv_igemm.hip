@@ -1258,13 +1258,25 @@ extern "C" int frmap_conv_igemm(const void* in, const void* w_packed, const floa
   return conv_igemm_impl(in, w_packed, shift, residual, out, B, Hi, Wi, Cin, Cout, K, stride, pad, relu, dtype, none, stream);
 }
 
+extern "C" int frmap_conv3x3_pp_layout(int B, int Hi, int Wi, int Cin, int Cout);
+
+// 1 = the fused-shortcut kernel takes the shape.  FRMAP_DS_UNFUSE_SMALL=1 (A/B switch) answers 0 where the
+// second-generation kernel (conv_pp.hip, no shortcut stages yet) would take the plain 3x3 layer and the maps are small
+// (14x14 / 7x7), so the caller runs the shortcut as its own 1x1 launch and feeds it as the residual.
 extern "C" int frmap_conv_igemm_ds_supported(int B, int Hi, int Wi, int Cin, int Cout, int ds_Hi, int ds_Wi, int ds_Cin,
                                              int ds_stride) {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("FRMAP_CONV_DSFUSE"); on = e ? atoi(e) : 1; }
+  static int on = -1, unfuse_small = 0;
+  if (on < 0) {
+    const char* e = getenv("FRMAP_CONV_DSFUSE");
+    on = e ? atoi(e) : 1;
+    const char* e2 = getenv("FRMAP_DS_UNFUSE_SMALL");
+    unfuse_small = e2 ? atoi(e2) : 0;   // measured a wash end to end (eager +0.2 %, graph replay -3 %): off by default
+  }
   if (!on || B <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cin % 32 || Cout <= 0 || Cout % 64) return 0;
   const DsArgs d = {(const void*)1, (const void*)1, ds_Hi, ds_Wi, ds_Cin, ds_stride};
-  return conv_ds_ok(B, Hi, Wi, Cin, Cout, d) ? 1 : 0;
+  if (!conv_ds_ok(B, Hi, Wi, Cin, Cout, d)) return 0;
+  if (unfuse_small && Hi * Wi <= 256 && frmap_conv3x3_pp_layout(B, Hi, Wi, Cin, Cout) != 0) return 0;
+  return 1;
 }
 
 extern "C" int frmap_conv_igemm_ds(const void* in, const void* w_packed, const float* shift, const void* ds_in,

@@ -285,6 +285,8 @@ static int pp_launch(const PPParams& p, hipStream_t st) {
   return 0;
 }
 
+// (in == nullptr: plan only - returns the layout the layer would take: 1 = 224 px x 256 ch, 2 = 448 px x 128 ch,
+//  3 = 224 px x 128 ch with the wave groups splitting K, 0 = not taken.)
 // Returns 1 if the layer was launched on conv3x3_pp_kernel, 0 if the shape is not taken (caller falls through to the
 // first-generation kernels), negative on a launch error.
 int frmap_conv3x3_pp(const void* in, const void* w_packed, const float* shift, const void* residual, void* out, int B, int Hi,
@@ -351,6 +353,7 @@ int frmap_conv3x3_pp(const void* in, const void* w_packed, const float* shift, c
   if (!nhp) return 0;
   p.tile_px = tpx; p.mtiles = mtl; p.ntiles = ntl;
   if (g_pp_on < 0 && (long long)mtl * ntl < min_tiles / 2) return 0;   // too few tiles even with split-K: the smaller first-generation tiles win
+  if (!in) return ks == 2 ? 3 : (bn == 256 ? 1 : 2);                   // plan-only query (frmap_conv3x3_pp_layout)
   int rc;
 #define PP_GO(TT)                                                                                               \
   (ks == 2 ? (nhp <= 4 ? pp_launch<TT, MI, 2, 4, 2>(p, st) : pp_launch<TT, MI, 2, 6, 2>(p, st))                  \
@@ -359,4 +362,9 @@ int frmap_conv3x3_pp(const void* in, const void* w_packed, const float* shift, c
   rc = dtype == FRMAP_BF16 ? PP_GO(BF16) : PP_GO(F16);
 #undef PP_GO
   return rc ? rc : 1;
+}
+
+extern "C" int frmap_conv3x3_pp_layout(int B, int Hi, int Wi, int Cin, int Cout) {
+  if (B <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  return frmap_conv3x3_pp(nullptr, nullptr, nullptr, nullptr, nullptr, B, Hi, Wi, Cin, Cout, 0, FRMAP_BF16, nullptr);
 }
