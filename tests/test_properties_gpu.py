@@ -1,7 +1,9 @@
 """GPU: size-independent properties at BASELINE.json's full per-GPU sizes and edge-case inputs
 (the CPU oracle is too slow there; these checks need no reference):
-  * per-face independence — a face's embedding does not depend on its batch neighbours (eval-mode BN),
-    so any sub-batch reproduces the big batch's rows bit-for-bit;
+  * per-face independence — a face's embedding does not depend on its batch neighbours (eval-mode BN):
+    any sub-batch reproduces the big batch's rows up to the fp32 summation order (the 3x3 kernels choose their tile
+    layout - pixel split, in-workgroup split-K, first-generation tiles - from the batch size), and bit-for-bit when the
+    same kernels run (equal batch sizes);
   * determinism — two runs are bit-identical;
   * enrolment round trip — probes matched against a gallery that contains their own embeddings come
     back with idx == own row and distance sqrt(D)*1e-6 (the eps term of F.pairwise_distance);
@@ -39,7 +41,12 @@ def test_full_size_batch_properties():
         assert torch.equal(emb, emb2)                                       # deterministic
         assert torch.allclose(emb.norm(dim=1), torch.ones(1024, device=DEV), atol=1e-4)
         for lo, hi in ((0, 1), (100, 117), (1000, 1024), (255, 257)):       # ragged sub-batches, incl. B == 1
-            assert torch.equal(m(x[lo:hi]), emb[lo:hi]), (lo, hi)           # per-face independence, bit-exact
+            sub = m(x[lo:hi])                                               # per-face independence
+            assert float((1 - torch.nn.functional.cosine_similarity(sub, emb[lo:hi], dim=1)).max()) < 2e-5, (lo, hi)
+            assert float((sub - emb[lo:hi]).abs().max()) < 2e-3, (lo, hi)
+        a = m(torch.cat([x[512:768], x[:256]]))                             # 512 faces; rows 256.. are faces 0..255
+        b = m(torch.cat([x[768:], x[:256]]))                                # same batch size, different neighbours
+        assert torch.equal(a[256:], b[256:])                                # same kernels: bit for bit
         gal[torch.arange(0, 10000, 10)[:1000]] = emb[:1000]                 # enrol the first 1000 probes
         idx, dist = ops.match_top1(emb, gal)
         assert torch.equal(idx[:1000].cpu(), torch.arange(0, 10000, 10)[:1000].int())
