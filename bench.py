@@ -145,6 +145,10 @@ def _conv_kernel_name(dt, Cin, k, stride, H, W, ds, Cout=0, B=0):
         lay = _lib.load().frmap_conv3x3_pp_layout(B, H, W, Cin, Cout)
         if lay:
             return f"conv3x3_pp_kernel<{dt}>"
+    if k == 3 and stride == 2 and not ds:
+        from frmap_amd import _lib
+        if _lib.load().frmap_conv3x3s2_pp_layout(B, H, W, Cin, Cout):
+            return f"conv3x3s2_pp_kernel<{dt}>"
     if ds:
         return f"conv3x3_fast_kernel<{dt}, true>"
     if k == 1:

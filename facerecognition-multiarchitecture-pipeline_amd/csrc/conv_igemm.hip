@@ -1139,6 +1139,12 @@ static int conv_igemm_impl(const void* in, const void* w_packed, const float* sh
     const int lds = p.halo_bytes + wbytes;
     return dtype == FRMAP_BF16 ? launch<BF16, 256, 1, 1>(p, lds, st) : launch<F16, 256, 1, 1>(p, lds, st);
   }
+  // 3x3 stride 2, even input sizes: the LDS-DMA ping-pong kernel with space-to-depth addressing when it takes the shape
+  if (stride == 2 && p.dbg == 0) {
+    const int rc = frmap_conv3x3s2_pp(in, w_packed, shift, residual, out, B, Hi, Wi, Cin, Cout, relu, dtype, st);
+    if (rc < 0) return rc;
+    if (rc == 1) return 0;
+  }
   // 3x3 stride 2 (even input height): row-parity split staging, two workgroups per CU
   if (stride == 2 && Hi % 2 == 0 && p.dbg == 0) {
     const int rows = (256 + Wo - 2) / Wo + 1, cross = (256 + Ho * Wo - 2) / (Ho * Wo);

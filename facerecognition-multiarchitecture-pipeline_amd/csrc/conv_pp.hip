@@ -252,9 +252,193 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
                             nt * BN + wn * 64, p.shift, (const elem*)p.res, (elem*)p.out, p.relu, lane);
 }
 
+// ================================================================================================
+// 3x3 STRIDE-2 convolutions (ResNet layer{2,3,4}.0.conv1) on the same pipeline, by space-to-depth ADDRESSING.
+//
+// out(oy, ox) reads in(2oy + kh - 1, 2ox + kw - 1).  Write 2oy + kh - 1 = 2(oy + a) + dy: kh = 0 -> (a, dy) = (-1, 1),
+// kh = 1 -> (0, 0), kh = 2 -> (0, 1), and the same for kw -> (b, dx).  For a fixed sub-position s = (dy, dx) the pixels
+// in(2y' + dy, 2x' + dx) form a HALF-resolution map, and the taps that read it are a stride-1 stencil over (a, b) in
+// {-1, 0}^2: sub-position (0,0) is read by 1 tap, (0,1) and (1,0) by 2 each, (1,1) by 4 - nine k-steps per 32-channel
+// chunk, exactly the layer's own, none padded.  So a chunk's k-steps walk FOUR small halo images (one per sub-position,
+// (rows + 1) x (Wo + 1) pixels: only a top / left border; 14 KB for a 14x14 output map, where the first-generation
+// kernel stages two 28 KB parity planes through registers), each DMA'd straight from the NHWC input with a per-lane base
+// pointer (position (2y', 2x')) plus a SCALAR offset ((dy * Wi + dx) * Cin + chunk * 32 elements).
+// Images live in four LDS slots (slot = sub-position); schedule per chunk (one phase per tap, t = 0..8):
+//   reads : t = 0 -> image 0 | t = 1,2 -> image 1 | t = 3,4 -> image 2 | t = 5..8 -> image 3
+//   DMA   : t = 1,2 -> image 3 of THIS chunk | t = 3,4 / 5,6 / 7,8 -> images 0 / 1 / 2 of the NEXT chunk
+//   every image is issued >= 2 phases after its slot's last reader and >= 2 phases before its first reader.
+// Everything else (slab ring, the two wave groups half a phase apart, counted waits, epilogue) is conv3x3_pp_kernel's.
+// ================================================================================================
+template <typename TT, int MI, int WM, int NHP2>
+__global__ __launch_bounds__(512, 2) void conv3x3s2_pp_kernel(const PPParams p) {
+  constexpr int NI = 4, WN = 8 / WM;
+  constexpr int TAPS = 9, BN = WN * 64, WB = BN * 64;
+  constexpr int NWI = (WB / 1024) / 8;
+  constexpr int RING = 4;
+  constexpr int HB = NHP2 * 8 * 1024;  // bytes of one sub-position image slot
+  constexpr int PPH = NHP2 >= 2 ? NHP2 / 2 : 1;  // halo pieces per wave and issuing phase (an image is issued over two phases)
+  using vec8 = typename TT::vec8;
+  using elem = typename TT::elem;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // LDS map: [image slot 0..3][slab 0..3]
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, q = wave & 3;
+  const int wn = WM == 4 ? (wave & 1) : q;
+  const int mslice = WM == 2 ? grp : grp * 2 + (q >> 1);
+  const int lr = lane & 15, g = lane >> 4;
+
+  const int L = pp_xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = L / p.ntiles, nt = L - mt * p.ntiles;
+  const int m0 = mt * p.tile_px, mend = min(m0 + p.tile_px, p.M);
+  const int nch = p.nchunks, nk = nch * TAPS;
+  const int Wo = p.Wi >> 1;
+  // (here p.Hp / p.Wp are the padded HALF-resolution sizes Ho + 1 / Wo + 1, p.HoWo = Ho * Wo, p.dWo divides by Wo)
+
+  const int n0 = frmap_div(m0, p.dHoWo), oy0 = frmap_div(m0 - n0 * p.HoWo, p.dWo);
+  const int n1 = frmap_div(mend - 1, p.dHoWo), oy1 = frmap_div(mend - 1 - n1 * p.HoWo, p.dWo);
+  const int nrows = (n1 - n0) * p.Hp + oy1 - oy0 + 2;
+  const int nitems = nrows * p.Wp * 4;
+
+  // ---- per-lane DMA sources: piece j of this wave = piece (wave + 8j) of an image; base = sub-position (0,0), chunk 0
+  const char* hsrc[NHP2];
+  unsigned hval = 0;  // bit j: the piece's pixel exists (not border / past the problem): the scalar offsets apply
+#pragma unroll
+  for (int j = 0; j < NHP2; ++j) {
+    const int item = ((wave + 8 * j) << 6) + lane;
+    const int px = item >> 2, ps = item & 3;
+    const int cg = ps ^ (((px >> 2) & 1) << 1);
+    const int r = (int)fast_div((uint32_t)px, p.magic_Wp);
+    const int c = px - r * p.Wp;
+    const int rr = oy0 + r;
+    const int dn = (int)fast_div((uint32_t)rr, p.magic_Hp);
+    const int yh = rr - dn * p.Hp - 1, xh = c - 1, n = n0 + dn;   // half-resolution position (y', x'); -1 = border
+    const bool ok = item < nitems && n < p.N && yh >= 0 && xh >= 0;
+    hsrc[j] = ok ? (const char*)p.in + ((((size_t)n * p.Hi + 2 * yh) * p.Wi + 2 * xh) * p.Cin + cg * 8) * sizeof(elem)
+                 : (const char*)g_pp_zero + cg * 16;
+    hval |= ok ? (1u << j) : 0u;
+  }
+  const int wblk = NWI == 2 ? (wave >> 1) : (wave >> 2);
+  const int wpart = NWI == 2 ? ((wave & 1) << 1) : (wave & 3);
+  const char* wsrc = (const char*)p.wpk + ((size_t)(nt * (BN / 64) + wblk) * p.nchunks * TAPS) * 4096 + wpart * 1024 + lane * 16;
+  const unsigned wdst = lds0 + 4 * HB + wblk * 4096 + wpart * 1024;
+  const unsigned hdst = lds0 + wave * 1024;
+  const int rowb = p.Wi * p.Cin * (int)sizeof(elem), pxb = p.Cin * (int)sizeof(elem);
+
+  // phase t of a chunk: original tap (kh*3 + kw) whose weights it uses, sub-position image, (a + 1, b + 1)
+  constexpr int TAP_OF[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};
+  constexpr int IMG_OF[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
+  constexpr int A1_OF[9] = {1, 1, 1, 0, 1, 0, 0, 1, 1};
+  constexpr int B1_OF[9] = {1, 0, 1, 1, 1, 0, 1, 0, 1};
+
+  auto issue_slab = [&](int ci, int t, int slot) {
+    const int cc = ci < nch ? ci : nch - 1;
+    const int tap = ci < nch ? TAP_OF[t] : 8;
+    const char* s = wsrc + (size_t)(cc * TAPS + tap) * 4096;
+    const unsigned d = wdst + (unsigned)slot * WB;
+    pp_dma16(s, d);
+    if (NWI == 2) pp_dma16(s + 1024, d + 1024);
+  };
+  auto issue_img = [&](int ci, int sp, int j) {  // piece j of sub-position image sp of chunk ci (past the end: zeros)
+    const int off = (sp >> 1) * rowb + (sp & 1) * pxb + ci * 64;
+    const bool live = ci < nch && ((hval >> j) & 1u);
+    const char* s = live ? hsrc[j] + off : (ci < nch ? hsrc[j] : (const char*)g_pp_zero);
+    pp_dma16(s, hdst + (unsigned)sp * HB + j * 8192);
+  };
+
+  // ---- prologue: images 0, 1, 2 of chunk 0 (image 3 rides in phases 1, 2), slabs of phases 0 and 1
+#pragma unroll
+  for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+    for (int j = 0; j < NHP2; ++j) issue_img(0, sp, j);
+  issue_slab(0, 0, 0);
+  issue_slab(0, 1, 1);
+
+  int A[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = min(m0 + (mslice * MI + mi) * 16 + lr, mend - 1);
+    const int n = frmap_div(m, p.dHoWo), rem = m - n * p.HoWo, oy = frmap_div(rem, p.dWo), ox = rem - oy * Wo;
+    A[mi] = ((((n - n0) * p.Hp + oy - oy0) * p.Wp + ox) << 6) | (g << 4);
+  }
+  const int woff = (lr << 6) + ((g ^ (((lr >> 2) & 1) << 1)) << 4);
+  const char* slabs = smem + 4 * HB + wn * 4096 + woff;
+
+  f32x4_t acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  pp_wait_vm<0>();
+  pp_barrier();
+  if (grp == 1) pp_barrier();
+
+  for (int ci = 0; ci < nch; ++ci) {
+    pp_static_for(std::make_integer_sequence<int, TAPS>{}, [&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      const int k = ci * TAPS + t;
+      vec8 wf[NI], pf[MI];
+      {
+        const char* sl = slabs + (k & (RING - 1)) * WB;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) wf[ni] = *(const vec8*)(sl + ni * 1024);
+        const char* hb = smem + IMG_OF[t] * HB;
+        const int toff = (A1_OF[t] * p.Wp + B1_OF[t]) << 6;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int at = A[mi] + toff;
+          pf[mi] = *(const vec8*)(hb + (at ^ ((at >> 3) & 32)));
+        }
+      }
+      // DMA of this phase: t = 1,2 image 3 of this chunk; t = 3,4 / 5,6 / 7,8 images 0 / 1 / 2 of the next chunk
+      constexpr int NH = t >= 1 ? ((NHP2 == 1 && ((t - 1) & 1)) ? 0 : PPH) : 0;
+      if (t >= 1) {
+        constexpr int qi = (t - 1) >> 1, h = (t - 1) & 1;
+#pragma unroll
+        for (int e = 0; e < NH; ++e) issue_img(qi == 0 ? ci : ci + 1, qi == 0 ? 3 : qi - 1, h * PPH + e);
+      }
+      issue_slab(t + 2 < TAPS ? ci : ci + 1, (t + 2) % TAPS, (k + 2) & (RING - 1));
+      pp_wait_vm<NWI + NH>();
+      pp_barrier();
+      pp_wait_lgkm0();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = TT::mfma(wf[ni], pf[mi], acc[mi][ni]);
+      pp_barrier();
+    });
+  }
+  if (grp == 0) pp_barrier();
+  pp_wait_vm<0>();
+  pp_barrier();
+
+  conv_epilogue<TT, MI, NI>(acc, smem + wave * (16 * (NI * 64 + 16)), m0 + mslice * (MI * 16), mend, p.Cout,
+                            nt * BN + wn * 64, p.shift, (const elem*)p.res, (elem*)p.out, p.relu, lane);
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// most halo rows any tile touches: rows of the stacked padded maps (hp rows per image) between the tile's first and last
+// output row, + extra (s1: 3 = one row above, one below; s2 half-resolution maps: 2) - evaluated exactly as the kernels
+// do, over one period of the tile start positions
+static int pp_max_rows(long long M, int tile_px, int howo, int wo, int hp, int extra) {
+  int best = 0;
+  const long long mtiles = (M + tile_px - 1) / tile_px;
+  const long long lim = mtiles < howo ? mtiles : howo;
+  for (long long mt = 0; mt < lim; ++mt) {
+    const long long m0 = mt * tile_px, mend = (m0 + tile_px < M ? m0 + tile_px : M) - 1;
+    const long long n0 = m0 / howo, n1 = mend / howo;
+    const int oy0 = (int)((m0 - n0 * howo) / wo), oy1 = (int)((mend - n1 * howo) / wo);
+    const int rows = (int)(n1 - n0) * hp + oy1 - oy0 + extra;
+    if (rows > best) best = rows;
+  }
+  return best;
+}
+
 static int pp_env(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
@@ -327,10 +511,7 @@ int frmap_conv3x3_pp(const void* in, const void* w_packed, const float* shift, c
     if (g_pp_px > 0 && g_pp_px <= cap) tile_px = g_pp_px;
     mtiles = (int)((Mll + tile_px - 1) / tile_px);
     ntiles = Cout / bn;
-    // halo rows a tile can touch: its output rows + 2, plus the padded-row jump at every image boundary it crosses
-    const int orows = (tile_px + Wi - 2) / Wi + 1;            // output rows touched (unaligned start)
-    const int cross = (tile_px + Hi * Wi - 2) / (Hi * Wi);    // image boundaries crossed
-    const long long hbytes = (long long)(orows + 2 + 2ll * cross) * p.Wp * 64;
+    const long long hbytes = (long long)pp_max_rows(Mll, tile_px, Hi * Wi, Wi, p.Hp, 3) * p.Wp * 64;
     if (hbytes / 64 >= 65536) return 0;
     const int per = (8 / ks) * 1024;                           // bytes one "piece per wave" adds to the image
     const int nhp = (int)((hbytes + per - 1) / per);
@@ -367,4 +548,78 @@ int frmap_conv3x3_pp(const void* in, const void* w_packed, const float* shift, c
 extern "C" int frmap_conv3x3_pp_layout(int B, int Hi, int Wi, int Cin, int Cout) {
   if (B <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0) return 0;
   return frmap_conv3x3_pp(nullptr, nullptr, nullptr, nullptr, nullptr, B, Hi, Wi, Cin, Cout, 0, FRMAP_BF16, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// stride-2 launcher (conv3x3s2_pp_kernel)
+// ------------------------------------------------------------------------------------------------
+template <typename TT, int MI, int WM, int NHP2>
+static int pp2_launch(const PPParams& p, hipStream_t st) {
+  auto kern = conv3x3s2_pp_kernel<TT, MI, WM, NHP2>;
+  if (frmap_big_lds((const void*)kern, 160 * 1024)) return -2;
+  int lds = 4 * NHP2 * 8192 + 4 * (8 / WM) * 64 * 64;
+  const int scratch = 8 * 16 * (4 * 64 + 16);
+  if (lds < scratch) lds = scratch;
+  hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles), dim3(512), lds, st, p);
+  FRMAP_LAUNCH_CHECK();
+  return 0;
+}
+
+// 3x3 stride-2 pad-1 layer: 1 = launched on conv3x3s2_pp_kernel, 0 = shape not taken, < 0 = error (in == nullptr: plan only)
+int frmap_conv3x3s2_pp(const void* in, const void* w_packed, const float* shift, const void* residual, void* out, int B, int Hi,
+                       int Wi, int Cin, int Cout, int relu, int dtype, hipStream_t st) {
+  static int on = -1, min_tiles = 200, min_cin = 64;
+  if (on < 0) {
+    min_tiles = pp_env("FRMAP_PP_MIN_TILES", 200);
+    min_cin = pp_env("FRMAP_PP_S2_MIN_CIN", 64);
+    on = pp_env("FRMAP_CONV_PP", 1) && pp_env("FRMAP_CONV_PP_S2", 1);
+  }
+  constexpr int MI = 7;
+  if (g_pp_on >= 0 ? !g_pp_on : (!on || Cin < min_cin)) return 0;
+  if (Hi % 2 || Wi % 2 || Cin % 32 || Cin > 1024 || Cout % 128) return 0;
+  const int Ho = Hi / 2, Wo = Wi / 2;
+  const long long Mll = (long long)B * Ho * Wo;
+  if (Mll >= (1ll << 31) || (long long)B * Hi * Wi * Cin * 2 >= (1ll << 46) || (long long)Hi * Wi * Cin * 2 >= (1ll << 31)) return 0;
+  int bn = Cout % 256 == 0 ? 256 : 128;
+  if (g_pp_bn == 128 || g_pp_bn == 256) bn = (g_pp_bn == 256 && Cout % 256) ? 128 : g_pp_bn;
+  const int cap = (bn == 256 ? 2 : 4) * MI * 16;
+  if (Wo > cap) return 0;
+  int tile_px;
+  if (Ho * Wo <= cap) tile_px = (cap / (Ho * Wo)) * Ho * Wo;
+  else {
+    int rows = cap / Wo;
+    for (int r = rows; r * 8 >= rows * 7 && r >= 1; --r)
+      if (Ho % r == 0) { rows = r; break; }
+    tile_px = rows * Wo;
+  }
+  if (g_pp_px > 0 && g_pp_px <= cap) tile_px = g_pp_px;
+  PPParams p;
+  p.in = in; p.wpk = w_packed; p.shift = shift; p.res = residual; p.out = out;
+  p.N = B; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
+  p.M = (int)Mll; p.HoWo = Ho * Wo; p.Hp = Ho + 1; p.Wp = Wo + 1;   // half-resolution maps carry a top / left border only
+  p.magic_Wp = frmap_magic((uint32_t)p.Wp); p.magic_Hp = frmap_magic((uint32_t)p.Hp);
+  p.dHoWo = frmap_div_make((uint32_t)p.HoWo); p.dWo = frmap_div_make((uint32_t)Wo);
+  p.nchunks = Cin / 32;
+  p.tile_px = tile_px;
+  p.mtiles = (int)((Mll + tile_px - 1) / tile_px);
+  p.ntiles = Cout / bn;
+  const long long hbytes = (long long)pp_max_rows(Mll, tile_px, Ho * Wo, Wo, p.Hp, 2) * p.Wp * 64;
+  if (hbytes / 64 >= 65536) return 0;
+  const int need = (int)((hbytes + 8191) / 8192);
+  const int nhp = need <= 1 ? 1 : (need <= 2 ? 2 : (need <= 4 ? 4 : 0));
+  if (!nhp || (nhp == 4 && bn == 256)) return 0;                       // (4 x 32 KB images + 4 x 16 KB slabs would not fit)
+  if (g_pp_on < 0 && (long long)p.mtiles * p.ntiles < min_tiles) return 0;
+  if (!in) return bn == 256 ? 1 : 2;
+  int rc;
+#define PP2_GO(TT)                                                                                                  \
+  (bn == 256 ? (nhp == 1 ? pp2_launch<TT, MI, 2, 1>(p, st) : pp2_launch<TT, MI, 2, 2>(p, st))                        \
+             : (nhp == 1 ? pp2_launch<TT, MI, 4, 1>(p, st) : nhp == 2 ? pp2_launch<TT, MI, 4, 2>(p, st) : pp2_launch<TT, MI, 4, 4>(p, st)))
+  rc = dtype == FRMAP_BF16 ? PP2_GO(BF16) : PP2_GO(F16);
+#undef PP2_GO
+  return rc ? rc : 1;
+}
+
+extern "C" int frmap_conv3x3s2_pp_layout(int B, int Hi, int Wi, int Cin, int Cout) {
+  if (B <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  return frmap_conv3x3s2_pp(nullptr, nullptr, nullptr, nullptr, nullptr, B, Hi, Wi, Cin, Cout, 0, FRMAP_BF16, nullptr);
 }

@@ -203,6 +203,9 @@ int frmap_big_lds(const void* kern, int bytes);
 // second-generation 3x3 stride-1 kernel (conv_pp.hip): 1 = launched, 0 = shape not taken, < 0 = error
 int frmap_conv3x3_pp(const void* in, const void* w_packed, const float* shift, const void* residual, void* out, int B, int Hi,
                      int Wi, int Cin, int Cout, int relu, int dtype, hipStream_t st);
+// the same for 3x3 stride-2 pad-1 layers with even input sizes (conv3x3s2_pp_kernel)
+int frmap_conv3x3s2_pp(const void* in, const void* w_packed, const float* shift, const void* residual, void* out, int B, int Hi,
+                       int Wi, int Cin, int Cout, int relu, int dtype, hipStream_t st);
 #define FRMAP_REQUIRE(cond, ...)        \
   do {                                  \
     if (!(cond)) {                      \

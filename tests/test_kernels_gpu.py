@@ -451,3 +451,44 @@ def test_conv_pp_kernel_shapes_and_tilings():
                 assert torch.allclose(y_pp.float(), y_g1.float(), atol=atol, rtol=rtol), (ci, dtype, "generations differ")
     finally:
         lib.frmap_conv_pp_tuning(-1, -1, -1)
+
+
+def test_conv_pp_stride2_kernel():
+    """The stride-2 form of the LDS-DMA ping-pong kernel (space-to-depth addressing: four half-resolution halo images
+    per 32-channel chunk, one to four taps each) against fp32 torch and against the first-generation row-parity kernel:
+    the three ResNet stride-2 shapes, ragged batches, tiles crossing image boundaries, odd aspect ratios, forced tile
+    sizes, both channel tiles, residual / activation variants."""
+    from frmap_amd import _lib
+    lib = _lib.load()
+    cases = [  # B, H, W, Cin, Cout, residual, act, tile_px, bn
+        (3, 28, 28, 128, 256, False, 1, -1, -1), (2, 56, 56, 64, 128, False, 1, -1, -1), (5, 14, 14, 256, 512, False, 1, -1, -1),
+        (5, 14, 14, 256, 512, True, 0, -1, 128), (2, 20, 36, 96, 128, True, 1, -1, -1), (4, 8, 6, 32, 128, False, 2, -1, -1),
+        (33, 14, 14, 128, 256, True, 1, 37, 256), (3, 28, 28, 128, 256, False, 1, 100, 128), (1, 2, 2, 64, 128, False, 1, -1, -1),
+        (2, 4, 112, 32, 128, True, 1, -1, -1), (7, 28, 12, 64, 256, False, 1, -1, -1),
+    ]
+    try:
+        for ci, (B, H, W, Cin, Cout, res, act, px, bn) in enumerate(cases):
+            for dtype in DTYPES:
+                x = synth.randn(9500 + ci, (B, Cin, H, W), "x").to(dtype)
+                w = (synth.randn(9600 + ci, (Cout, Cin, 3, 3), "w") * math.sqrt(2.0 / (Cin * 9))).to(dtype)
+                shift = synth.randn(9700 + ci, (Cout,), "b") * 0.1
+                ref = F.conv2d(x.float(), w.float(), None, stride=2, padding=1) + shift.view(1, -1, 1, 1)
+                r = synth.randn(9800 + ci, tuple(ref.shape), "r").to(dtype) if res else None
+                if res:
+                    ref = ref + r.float()
+                ref = F.relu(ref) if act == 1 else (F.gelu(ref) if act == 2 else ref)
+                wpk = ops.pack_conv_weight(w.float().to(DEV), dtype)
+                xin, rin = _nhwc(x).to(DEV), (_nhwc(r).to(DEV) if res else None)
+                assert lib.frmap_conv_pp_tuning(1, px, bn) == 0
+                assert lib.frmap_conv3x3s2_pp_layout(B, H, W, Cin, Cout) in (1, 2), (ci, "not taken")
+                y_pp = ops.conv_igemm(xin, wpk, shift.to(DEV), Cout, 3, 2, 1, act, rin)
+                atol, rtol = _tol(dtype)
+                y = y_pp.float().cpu().permute(0, 3, 1, 2)
+                assert y.shape == ref.shape
+                assert torch.allclose(y, ref, atol=atol, rtol=rtol), (ci, dtype, float((y - ref).abs().max()))
+                if min(H, W) >= 4:   # (the first-generation stride-2 kernels do not take 2-pixel-wide inputs)
+                    lib.frmap_conv_pp_tuning(0, -1, -1)
+                    y_g1 = ops.conv_igemm(xin, wpk, shift.to(DEV), Cout, 3, 2, 1, act, rin)
+                    assert torch.allclose(y_pp.float(), y_g1.float(), atol=atol, rtol=rtol), (ci, dtype, "generations differ")
+    finally:
+        lib.frmap_conv_pp_tuning(-1, -1, -1)
