@@ -190,7 +190,11 @@ def instrument(ops, torch, dt):
         M = out.shape[0] * out.shape[1] * out.shape[2]
         flop = 2.0 * M * Cout * (Cin * 9 + x_ds.shape[3])
         gathered = M * x_ds.shape[3] * x_ds.element_size()      # only the strided pixels are needed
-        return _conv_kernel_name(dt, Cin, 3, 1, H, W, True), flop, _nbytes(x) + _nbytes(out) + _nbytes(wpk) + _nbytes(wpk_ds) + gathered
+        from frmap_amd import _lib
+        name = _conv_kernel_name(dt, Cin, 3, 1, H, W, True)
+        if _lib.load().frmap_conv3x3_pp_ds_layout(B, H, W, Cin, Cout, x_ds.shape[1], x_ds.shape[2], x_ds.shape[3], ds_stride):
+            name = f"conv3x3_pp_kernel<{dt}, DS>"
+        return name, flop, _nbytes(x) + _nbytes(out) + _nbytes(wpk) + _nbytes(wpk_ds) + gathered
 
     def d_stem(out, x, wpk, shift, dtype, pool3=True):
         B, _, H, W = x.shape

@@ -36,6 +36,7 @@ PROTOTYPES = {
     "frmap_conv_pp_tuning": (_i, [_i, _i, _i]),
     "frmap_conv3x3_pp_layout": (_i, [_i, _i, _i, _i, _i]),
     "frmap_conv3x3s2_pp_layout": (_i, [_i, _i, _i, _i, _i]),
+    "frmap_conv3x3_pp_ds_layout": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "frmap_conv_igemm_ds_supported": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "frmap_conv_igemm_ds": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "frmap_linear_mfma_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -1177,8 +1177,9 @@ static int conv_igemm_impl(const void* in, const void* w_packed, const float* sh
     }
   }
   // 3x3 stride 1 with Cin >= 128: the LDS-DMA ping-pong kernel (conv_pp.hip) when it takes the shape
-  if (stride == 1 && !ds.in && p.dbg == 0) {
-    const int rc = frmap_conv3x3_pp(in, w_packed, shift, residual, out, B, Hi, Wi, Cin, Cout, relu, dtype, st);
+  if (stride == 1 && p.dbg == 0) {
+    const FrmapPPShortcut sc = {ds.in, ds.w, ds.Hi, ds.Wi, ds.Cin, ds.stride};
+    const int rc = frmap_conv3x3_pp(in, w_packed, shift, residual, out, B, Hi, Wi, Cin, Cout, relu, dtype, st, ds.in ? &sc : nullptr);
     if (rc < 0) return rc;
     if (rc == 1) return 0;
   }

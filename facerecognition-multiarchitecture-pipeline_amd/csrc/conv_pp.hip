@@ -43,6 +43,10 @@ struct PPParams {
   int nchunks;    // Cin / 32
   int tile_px;    // output pixels per tile (<= 2 * MI * 16)
   int mtiles, ntiles;
+  // fused 1x1 projection shortcut (DS = true): out += W_ds . x_ds[n, oy * s, ox * s, :]  (extra one-tap k-steps at the end)
+  const void* ds_in;   // [N][ds_Hi][ds_Wi][ds_Cin]
+  const void* ds_w;    // packed like a 1x1 conv: [Cout/64][ds_Cin/32][1][64][4][8]
+  int ds_Hi, ds_Wi, ds_Cin, ds_stride, dsc;   // dsc = ds_Cin / 32
 };
 
 __device__ __attribute__((aligned(4096))) unsigned int g_pp_zero[1024];
@@ -84,9 +88,22 @@ __device__ __forceinline__ void pp_static_for(std::integer_sequence<int, Is...>,
 //         channels, each group covers ALL of it (2 pixel slices x 2 channel slices) but only every second chunk, with its
 //         own halo buffers and slab ring; at the end group B hands its accumulators to group A through LDS.  Twice the
 //         tiles of the KS = 1 layouts at the same per-wave MFMA shape and the same bytes staged per MFMA.
-template <typename TT, int MI, int WM, int NHP, int KS>
+// DS = true (KS = 1 only) folds a ResNet projection shortcut into the layer: out = act(conv3x3(in) + W_ds . x_ds(strided) +
+// shift), i.e. BasicBlock.conv2 + bn2 + downsample(conv1x1 s2 + bn) + add + ReLU in one launch.  The shortcut's K dimension
+// runs as dsc = ds_Cin/32 extra one-tap phases after the main loop.  Their pixel operand is a GATHER image (the tile's own
+// pixels, 64 B each, fetched at (oy*s, ox*s) of x_ds) in a ring of three buffers: the halo buffer the last main chunk does
+// not use, an extra buffer behind the slabs, and the last main chunk's halo buffer once that chunk is done; image d + 2 is
+// issued in shortcut phase d (images 0 and 1 ride in the last main chunk's idle DMA slots), and the phases that read a
+// buffer last retire their reads BEFORE their barrier, so the DMA issued one phase later cannot overtake them.
+template <typename TT, int MI, int WM, int NHP, int KS, bool DS>
 __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
+  static_assert(!(DS && KS == 2), "the fused shortcut is built for the pixel-split layouts only");
   constexpr int NI = 4, WN = KS == 2 ? 2 : 8 / WM;
+  constexpr int CAP = WM * MI * 16;                          // pixels a tile can hold (KS = 1)
+  constexpr int NGP = DS ? (CAP / 16 + 7) / 8 : 0;           // gather pieces per wave and shortcut image
+  constexpr int GBYTES = NGP * 8 * 1024;                     // bytes of one gather image buffer
+  constexpr int XT = DS ? 8 - NHP : 1;                       // idle DMA taps of a main chunk (NHP + 1 .. 8) image 1 can ride in
+  constexpr int PPT = DS ? (NGP + XT - 1) / XT : 0;          // ... pieces per such tap
   constexpr int TAPS = 9, BN = WN * 64, WB = BN * 64;      // slab bytes: BN channels x 32 channels x 2 B
   constexpr int GW = 8 / KS;                                 // waves that share one set of LDS buffers
   constexpr int NWI = (WB / 1024) / GW;                      // slab DMA instructions per wave and k-step (2, or 1 for BN = 128 / KS = 1)
@@ -144,16 +161,56 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
   const unsigned wdst = lds0 + gbase + 2 * HB + wblk * 4096 + wpart * 1024;  // + slot * WB
   const unsigned hdst = lds0 + gbase + gw * 1024;                              // + buffer * HB + j * GW * 1024
 
-  // group-local k-step kk = (chunk counter ci, tap t) -> the layer's k-step (chunk * 9 + t)
-  auto issue_slab = [&](int ci, int t, int slot) {  // (past the end: a dummy copy of the last slab into a slot nobody reads)
-    const int cc = ci < nch ? ci : nch - 1;
-    const int chunk = KS == 2 ? grp + 2 * cc : cc;
-    const char* s = wsrc + (size_t)(chunk * TAPS + (ci < nch ? t : TAPS - 1)) * 4096;
+  // shortcut (DS): gather piece e of this wave = piece (wave + 8e) of the image: lane -> tile pixel (piece*16 + lane/4)
+  const char* gsrc[DS ? NGP : 1];
+  const char* wsrc_ds = nullptr;
+  if (DS) {
+    const size_t img = (size_t)p.ds_Hi * p.ds_Wi * p.ds_Cin;
+#pragma unroll
+    for (int e = 0; e < NGP; ++e) {
+      const int item = ((wave + 8 * e) << 6) + lane;
+      const int px = item >> 2, ps = item & 3;
+      const int cg = ps ^ (((px >> 2) & 1) << 1);
+      const int m = m0 + px;
+      const int n = frmap_div(min(m, p.M - 1), p.dHoWo), rem = min(m, p.M - 1) - n * p.HoWo, oy = frmap_div(rem, p.dWo), ox = rem - oy * p.Wi;
+      gsrc[e] = (px < CAP && m < mend)
+                    ? (const char*)p.ds_in + ((size_t)n * img + ((size_t)(oy * p.ds_stride) * p.ds_Wi + ox * p.ds_stride) * p.ds_Cin + cg * 8) * sizeof(elem)
+                    : (const char*)g_pp_zero + cg * 16;
+    }
+    wsrc_ds = (const char*)p.ds_w + ((size_t)(nt * (BN / 64) + wblk) * p.dsc) * 4096 + wpart * 1024 + lane * 16;
+  }
+  // gather buffer of shortcut image d: ring {idle halo buffer, extra buffer behind the slabs, the last main chunk's halo buffer}
+  auto gbuf = [&](int d) -> unsigned {
+    const int r = d % 3;
+    return r == 0 ? (unsigned)(nch & 1) * HB : (r == 1 ? (unsigned)(2 * HB + RING * WB) : (unsigned)((nch - 1) & 1) * HB);
+  };
+  auto issue_gather = [&](int d, int e) {  // piece e of shortcut image d (past the last image: zeros into a buffer nobody reads)
+    const char* s = d < p.dsc ? gsrc[e] + (size_t)d * 64 : (const char*)g_pp_zero;
+    pp_dma16(s, lds0 + gbuf(d) + wave * 1024 + e * 8192);
+  };
+
+  // group-local k-step kk = (chunk counter ci, tap t) -> the layer's k-step (chunk * 9 + t); past the main loop: the
+  // shortcut's slabs (DS), then a dummy copy of the last slab into a slot nobody reads
+  auto issue_slab = [&](int ci, int t, int slot) {
     const unsigned d = wdst + (unsigned)slot * WB;
+    const char* s;
+    if (DS && ci >= nch) {
+      const int dk = (ci - nch) * TAPS + t;   // shortcut phase this slab belongs to
+      s = wsrc_ds + (size_t)(dk < p.dsc ? dk : p.dsc - 1) * 4096;
+    } else {
+      const int cc = ci < nch ? ci : nch - 1;
+      const int chunk = KS == 2 ? grp + 2 * cc : cc;
+      s = wsrc + (size_t)(chunk * TAPS + (ci < nch ? t : TAPS - 1)) * 4096;
+    }
     pp_dma16(s, d);
     if (NWI == 2) pp_dma16(s + 1024, d + 1024);
   };
-  auto issue_halo = [&](int ci, int j) {  // piece j of the group's chunk ci (past the last chunk: zeros into the idle buffer)
+  auto issue_halo = [&](int ci, int j) {  // piece j of the group's chunk ci; past the last chunk: shortcut image 0 (DS) or zeros
+    if (DS && ci >= nch) {
+      if (j < NGP) issue_gather(0, j);
+      else pp_dma16((const char*)g_pp_zero, hdst + (unsigned)(ci & 1) * HB + j * (GW * 1024));
+      return;
+    }
     const int chunk = KS == 2 ? grp + 2 * ci : ci;
     const char* s = ci < nch ? hsrc[j] + (size_t)chunk * 64 : (const char*)g_pp_zero;
     pp_dma16(s, hdst + (unsigned)(ci & 1) * HB + j * (GW * 1024));
@@ -189,6 +246,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
 
   for (int ci = 0; ci < nch; ++ci) {
     const char* hb = halo + (ci & 1) * HB;
+    if (DS) {   // the shortcut variant is short of registers: recompute the 63 per-tap fragment addresses (3 VALU each)
+#pragma unroll  // instead of letting the compiler keep them live across the loop
+      for (int mi = 0; mi < MI; ++mi) asm volatile("" : "+v"(A[mi]));
+    }
     pp_static_for(std::make_integer_sequence<int, TAPS>{}, [&](auto tc) {
       constexpr int t = decltype(tc)::value;
       const int k = ci * TAPS + t;
@@ -207,8 +268,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
       }
       constexpr bool HP = t >= 1 && t <= NHP;   // (no halo DMA at tap 0: the other group may still be reading that buffer's last tap)
       if (HP) issue_halo(ci + 1, t - 1);
+      // DS: shortcut image 1 rides in the idle taps NHP+1.. of the LAST main chunk (other chunks: dummy copies, so that
+      // the DMA count per phase - and with it every s_waitcnt immediate - is the same in every chunk)
+      constexpr int XE = (DS && t > NHP) ? ((t - NHP - 1) * PPT < NGP ? (NGP - (t - NHP - 1) * PPT < PPT ? NGP - (t - NHP - 1) * PPT : PPT) : 0) : 0;
+#pragma unroll
+      for (int e = 0; e < XE; ++e) {
+        if (ci == nch - 1) issue_gather(1, (t - NHP - 1) * PPT + e);
+        else pp_dma16((const char*)g_pp_zero, lds0 + 2 * HB + RING * WB + wave * 1024 + ((t - NHP - 1) * PPT + e) * 8192);
+      }
       issue_slab(t + 2 < TAPS ? ci : ci + 1, (t + 2) % TAPS, (k + 2) & (RING - 1));
-      pp_wait_vm<NWI + (HP ? 1 : 0)>();  // everything older than this phase's DMA has landed (slab k+1; next halo by t = 8)
+      pp_wait_vm<NWI + (HP ? 1 : 0) + XE>();  // everything older than this phase's DMA has landed (slab k+1; next halo by t = 8)
+      if (DS && t == TAPS - 1) pp_wait_lgkm0();  // (the first shortcut phase re-targets this chunk's halo buffer: retire its reads here)
       pp_barrier();
       // ---------------- MFMA(k)
       pp_wait_lgkm0();
@@ -219,6 +289,39 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
         for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = TT::mfma(wf[ni], pf[mi], acc[mi][ni]);
       pp_barrier();
     });
+  }
+  if (DS) {
+    // ---------------- shortcut phases: one 32-channel one-tap k-step each (k = nk + d)
+    int Ag[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int at = ((((mslice * MI + mi) << 4) + lr) << 6) | (g << 4);
+      Ag[mi] = at ^ ((at >> 3) & 32);
+    }
+    for (int d = 0; d < p.dsc; ++d) {
+      const int k = nk + d;
+      vec8 wf[NI], pf[MI];
+      {
+        const char* sl = slabs + (k & (RING - 1)) * WB;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) wf[ni] = *(const vec8*)(sl + ni * 1024);
+        const char* gb = smem + gbuf(d);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) pf[mi] = *(const vec8*)(gb + Ag[mi]);
+      }
+#pragma unroll
+      for (int e = 0; e < NGP; ++e) issue_gather(d + 2, e);
+      issue_slab(nch + (d + 2) / TAPS, (d + 2) % TAPS, (k + 2) & (RING - 1));
+      pp_wait_vm<NWI + NGP>();
+      pp_wait_lgkm0();   // retired before the barrier: the next phase's DMA re-targets the buffer image d - 1 ... d + 2 share
+      pp_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = TT::mfma(wf[ni], pf[mi], acc[mi][ni]);
+      pp_barrier();
+    }
   }
   if (grp == 0) pp_barrier();  // balance group B's extra start barrier
   pp_wait_vm<0>();             // the dummy DMA of the last two phases must not land in the buffers reused below
@@ -454,12 +557,12 @@ extern "C" int frmap_conv_pp_tuning(int enable, int tile_px, int bn) {
   return 0;
 }
 
-template <typename TT, int MI, int WM, int NHP, int KS>
+template <typename TT, int MI, int WM, int NHP, int KS, bool DS = false>
 static int pp_launch(const PPParams& p, hipStream_t st) {
-  auto kern = conv3x3_pp_kernel<TT, MI, WM, NHP, KS>;
+  auto kern = conv3x3_pp_kernel<TT, MI, WM, NHP, KS, DS>;
   if (frmap_big_lds((const void*)kern, 160 * 1024)) return -2;
   const int wb = (KS == 2 ? 2 : 8 / WM) * 64 * 64;
-  int lds = KS * (2 * NHP * (8 / KS) * 1024 + 4 * wb);
+  int lds = KS * (2 * NHP * (8 / KS) * 1024 + 4 * wb) + (DS ? ((WM * MI + 7) / 8) * 8192 : 0);
   const int scratch = 8 * 16 * (4 * 64 + 16);
   const int xch = KS == 2 ? 4 * MI * 4 * 1024 : 0;
   if (lds < scratch) lds = scratch;
@@ -474,7 +577,7 @@ static int pp_launch(const PPParams& p, hipStream_t st) {
 // Returns 1 if the layer was launched on conv3x3_pp_kernel, 0 if the shape is not taken (caller falls through to the
 // first-generation kernels), negative on a launch error.
 int frmap_conv3x3_pp(const void* in, const void* w_packed, const float* shift, const void* residual, void* out, int B, int Hi,
-                     int Wi, int Cin, int Cout, int relu, int dtype, hipStream_t st) {
+                     int Wi, int Cin, int Cout, int relu, int dtype, hipStream_t st, const FrmapPPShortcut* ds) {
   static int on = -1, force_px = 0, force_bn = 0, min_cin = 128, min_tiles = 200;
   if (on < 0) {
     min_tiles = pp_env("FRMAP_PP_MIN_TILES", 200);  // fewer tiles than this leave CUs idle: the first-generation kernels' smaller tiles win
@@ -495,6 +598,21 @@ int frmap_conv3x3_pp(const void* in, const void* w_packed, const float* shift, c
   p.magic_Wp = frmap_magic((uint32_t)p.Wp); p.magic_Hp = frmap_magic((uint32_t)p.Hp);
   p.dHoWo = frmap_div_make((uint32_t)p.HoWo); p.dWo = frmap_div_make((uint32_t)Wi);
   p.nchunks = Cin / 32;
+  p.ds_in = nullptr; p.ds_w = nullptr; p.ds_Hi = p.ds_Wi = p.ds_Cin = p.ds_stride = p.dsc = 0;
+  const bool has_ds = ds != nullptr;
+  if (has_ds) {
+    if (residual || ds->Cin <= 0 || ds->Cin % 32 || ds->stride < 1 || (ds->Hi - 1) / ds->stride + 1 != Hi ||
+        (ds->Wi - 1) / ds->stride + 1 != Wi || (long long)B * ds->Hi * ds->Wi * ds->Cin * 2 >= (1ll << 46))
+      return 0;
+    // A/B switch, OFF by default: parity-green, but end to end it only ties the first-generation fused kernel (layers 2 / 3
+    // at 256 faces: 71 us vs 71 us per launch) - the dummy DMA slots it adds to every main chunk and the recomputed
+    // fragment addresses lengthen the LOAD segments by about what the faster MFMA phases save
+    static int ds_on = -1;
+    if (ds_on < 0) ds_on = pp_env("FRMAP_CONV_PP_DS", 0);
+    if (!ds_on && g_pp_on < 0) return 0;
+    p.ds_in = ds->in; p.ds_w = ds->w; p.ds_Hi = ds->Hi; p.ds_Wi = ds->Wi; p.ds_Cin = ds->Cin; p.ds_stride = ds->stride;
+    p.dsc = ds->Cin / 32;
+  }
   // A layout = (pixels a tile can hold, channel tile, split-K groups).  Pixels per tile: whole images when they fit
   // (7x7: 4 per 224, 14x14: 1), else whole rows - a divisor of the image height when one is within 1/8 of the capacity
   // (28 rows, capacity 16 rows: 14), so tiles do not straddle images.  Returns the halo pieces (KB / waves) needed, 0 = no fit.
@@ -523,7 +641,7 @@ int frmap_conv3x3_pp(const void* in, const void* w_packed, const float* shift, c
   if (g_pp_bn == 128 || g_pp_bn == 256) bn_pref = (g_pp_bn == 256 && Cout % 256) ? 128 : g_pp_bn;
   int tpx = 0, mtl = 0, ntl = 0, ks = 1, bn = bn_pref;
   int nhp = plan(bn == 256 ? 2 * MI * 16 : 4 * MI * 16, bn, 1, tpx, mtl, ntl);
-  const bool want_ks2 = g_pp_ks == 2 || (g_pp_ks < 0 && (!nhp || (long long)mtl * ntl < min_tiles));
+  const bool want_ks2 = !has_ds && (g_pp_ks == 2 || (g_pp_ks < 0 && (!nhp || (long long)mtl * ntl < min_tiles)));
   if (want_ks2 && g_pp_ks != 1) {
     int t2 = 0, m2 = 0, n2 = 0;
     const int nhp2 = plan(2 * MI * 16, 128, 2, t2, m2, n2);
@@ -534,8 +652,17 @@ int frmap_conv3x3_pp(const void* in, const void* w_packed, const float* shift, c
   if (!nhp) return 0;
   p.tile_px = tpx; p.mtiles = mtl; p.ntiles = ntl;
   if (g_pp_on < 0 && (long long)mtl * ntl < min_tiles / 2) return 0;   // too few tiles even with split-K: the smaller first-generation tiles win
+  if (has_ds && (long long)mtl * ntl < min_tiles && g_pp_on < 0) return 0;   // (no split-K form of the shortcut kernel)
   if (!in) return ks == 2 ? 3 : (bn == 256 ? 1 : 2);                   // plan-only query (frmap_conv3x3_pp_layout)
   int rc;
+  if (has_ds) {   // pixel-split layouts only; the 448-pixel layout needs the 40 KB halo buffers to hold a gather image
+#define PPD_GO(TT)                                                                                                       \
+  (bn == 256 ? (nhp <= 3 ? pp_launch<TT, MI, 2, 3, 1, true>(p, st) : pp_launch<TT, MI, 2, 5, 1, true>(p, st))              \
+             : pp_launch<TT, MI, 4, 5, 1, true>(p, st))
+    rc = dtype == FRMAP_BF16 ? PPD_GO(BF16) : PPD_GO(F16);
+#undef PPD_GO
+    return rc ? rc : 1;
+  }
 #define PP_GO(TT)                                                                                               \
   (ks == 2 ? (nhp <= 4 ? pp_launch<TT, MI, 2, 4, 2>(p, st) : pp_launch<TT, MI, 2, 6, 2>(p, st))                  \
    : bn == 256 ? (nhp <= 3 ? pp_launch<TT, MI, 2, 3, 1>(p, st) : pp_launch<TT, MI, 2, 5, 1>(p, st))              \
@@ -547,7 +674,14 @@ int frmap_conv3x3_pp(const void* in, const void* w_packed, const float* shift, c
 
 extern "C" int frmap_conv3x3_pp_layout(int B, int Hi, int Wi, int Cin, int Cout) {
   if (B <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0) return 0;
-  return frmap_conv3x3_pp(nullptr, nullptr, nullptr, nullptr, nullptr, B, Hi, Wi, Cin, Cout, 0, FRMAP_BF16, nullptr);
+  return frmap_conv3x3_pp(nullptr, nullptr, nullptr, nullptr, nullptr, B, Hi, Wi, Cin, Cout, 0, FRMAP_BF16, nullptr, nullptr);
+}
+
+// the same question for the layer with a fused 1x1 stride-s projection shortcut (frmap_conv_igemm_ds)
+extern "C" int frmap_conv3x3_pp_ds_layout(int B, int Hi, int Wi, int Cin, int Cout, int ds_Hi, int ds_Wi, int ds_Cin, int ds_stride) {
+  if (B <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  const FrmapPPShortcut d = {nullptr, nullptr, ds_Hi, ds_Wi, ds_Cin, ds_stride};
+  return frmap_conv3x3_pp(nullptr, nullptr, nullptr, nullptr, nullptr, B, Hi, Wi, Cin, Cout, 0, FRMAP_BF16, nullptr, &d);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -201,8 +201,13 @@ void frmap_set_error(const char* fmt, ...);
 // raise a kernel's dynamic-LDS limit on the CURRENT device (once per (kernel, device)); 0 or -2 with the error set
 int frmap_big_lds(const void* kern, int bytes);
 // second-generation 3x3 stride-1 kernel (conv_pp.hip): 1 = launched, 0 = shape not taken, < 0 = error
+struct FrmapPPShortcut {  // fused 1x1 projection shortcut: out += W . x[n, oy * stride, ox * stride, :]
+  const void* in;
+  const void* w;  // packed as a 1x1 conv
+  int Hi, Wi, Cin, stride;
+};
 int frmap_conv3x3_pp(const void* in, const void* w_packed, const float* shift, const void* residual, void* out, int B, int Hi,
-                     int Wi, int Cin, int Cout, int relu, int dtype, hipStream_t st);
+                     int Wi, int Cin, int Cout, int relu, int dtype, hipStream_t st, const FrmapPPShortcut* ds);
 // the same for 3x3 stride-2 pad-1 layers with even input sizes (conv3x3s2_pp_kernel)
 int frmap_conv3x3s2_pp(const void* in, const void* w_packed, const float* shift, const void* residual, void* out, int B, int Hi,
                        int Wi, int Cin, int Cout, int relu, int dtype, hipStream_t st);

@@ -133,6 +133,8 @@ int frmap_conv_pp_tuning(int enable, int tile_px, int bn);
 int frmap_conv3x3_pp_layout(int B, int Hi, int Wi, int Cin, int Cout);
 /* The same question for a 3x3 stride-2 pad-1 layer (conv3x3s2_pp_kernel: 1 = 224 px x 256 ch, 2 = 448 px x 128 ch). */
 int frmap_conv3x3s2_pp_layout(int B, int Hi, int Wi, int Cin, int Cout);
+/* ... and for frmap_conv_igemm_ds (3x3 stride-1 layer with a fused 1x1 stride-s projection shortcut): 0 / 1 / 2. */
+int frmap_conv3x3_pp_ds_layout(int B, int Hi, int Wi, int Cin, int Cout, int ds_Hi, int ds_Wi, int ds_Cin, int ds_stride);
 
 /* A 3x3 stride-1 pad-1 convolution with a ResNet projection shortcut folded in (BasicBlock.conv2 + bn2 + downsample
  * [conv1x1 stride s + bn] + add + ReLU of the first block of a stage, torchvision resnet.py via face_models.py:67):

@@ -492,3 +492,41 @@ def test_conv_pp_stride2_kernel():
                     assert torch.allclose(y_pp.float(), y_g1.float(), atol=atol, rtol=rtol), (ci, dtype, "generations differ")
     finally:
         lib.frmap_conv_pp_tuning(-1, -1, -1)
+
+
+def test_conv_pp_fused_shortcut():
+    """conv3x3_pp_kernel<..., DS = true>: BasicBlock.conv2 + projection shortcut (extra one-tap phases fed by a gathered
+    image of the strided input) against fp32 torch and the first-generation fused kernel: the three ResNet shapes, both
+    pixel-split layouts, ragged batches, a stride-1 projection, shortcut depths of 1..8 chunks, forced tile sizes."""
+    from frmap_amd import _lib
+    lib = _lib.load()
+    cases = [  # B, H, W, Cin, Cout, dsC, s, act, tile_px, bn
+        (3, 28, 28, 128, 128, 64, 2, 1, -1, -1), (5, 14, 14, 256, 256, 128, 2, 1, -1, -1), (9, 7, 7, 512, 512, 256, 2, 1, -1, 256),
+        (2, 14, 14, 128, 256, 128, 1, 1, -1, -1), (5, 14, 14, 256, 256, 128, 2, 0, -1, 128), (4, 10, 6, 64, 128, 32, 2, 2, -1, -1),
+        (33, 7, 7, 128, 256, 96, 2, 1, 37, 256), (2, 28, 28, 128, 128, 128, 1, 1, 300, -1), (1, 3, 5, 256, 128, 256, 2, 1, -1, -1),
+    ]
+    try:
+        for ci, (B, H, W, Cin, Cout, dsC, sd, act, px, bn) in enumerate(cases):
+            for dtype in DTYPES:
+                h = synth.randn(9900 + ci, (B, Cin, H, W), "h").to(dtype)
+                xd = synth.randn(9910 + ci, (B, dsC, (H - 1) * sd + 1 + (sd - 1), (W - 1) * sd + 1 + (sd - 1)), "xd").to(dtype)
+                w = (synth.randn(9920 + ci, (Cout, Cin, 3, 3), "w") * math.sqrt(2.0 / (Cin * 9))).to(dtype)
+                wd = (synth.randn(9930 + ci, (Cout, dsC, 1, 1), "wd") * math.sqrt(1.0 / dsC)).to(dtype)
+                shift = synth.randn(9940 + ci, (Cout,), "b") * 0.1
+                ref = F.conv2d(h.float(), w.float(), None, padding=1) + F.conv2d(xd.float(), wd.float(), None, stride=sd) + shift.view(1, -1, 1, 1)
+                ref = F.relu(ref) if act == 1 else (F.gelu(ref) if act == 2 else ref)
+                assert ops.conv_ds_supported(B, H, W, Cin, Cout, xd.shape[2], xd.shape[3], dsC, sd)
+                args = (_nhwc(h).to(DEV), ops.pack_conv_weight(w.float().to(DEV), dtype), shift.to(DEV), Cout,
+                        _nhwc(xd).to(DEV), ops.pack_conv_weight(wd.float().to(DEV), dtype), sd, act)
+                lib.frmap_conv_pp_tuning(1, px, bn)
+                assert lib.frmap_conv3x3_pp_ds_layout(B, H, W, Cin, Cout, xd.shape[2], xd.shape[3], dsC, sd) in (1, 2), (ci, "not taken")
+                y_pp = ops.conv_igemm_ds(*args)
+                lib.frmap_conv_pp_tuning(0, -1, -1)
+                y_g1 = ops.conv_igemm_ds(*args)
+                atol, rtol = _tol(dtype)
+                y = y_pp.float().cpu().permute(0, 3, 1, 2)
+                assert y.shape == ref.shape
+                assert torch.allclose(y, ref, atol=atol, rtol=rtol), (ci, dtype, float((y - ref).abs().max()))
+                assert torch.allclose(y_pp.float(), y_g1.float(), atol=atol, rtol=rtol), (ci, dtype, "generations differ")
+    finally:
+        lib.frmap_conv_pp_tuning(-1, -1, -1)
