@@ -95,9 +95,15 @@ __device__ __forceinline__ void pp_static_for(std::integer_sequence<int, Is...>,
 // not use, an extra buffer behind the slabs, and the last main chunk's halo buffer once that chunk is done; image d + 2 is
 // issued in shortcut phase d (images 0 and 1 ride in the last main chunk's idle DMA slots), and the phases that read a
 // buffer last retire their reads BEFORE their barrier, so the DMA issued one phase later cannot overtake them.
-template <typename TT, int MI, int WM, int NHP, int KS, bool DS>
+// IM = true (A/B variant, measured 4-6 % slower: an LDS-DMA instruction between MFMAs stalls the issuing wave ~60 cycles and
+// the matrix pipe with it): this phase's DMA (one halo piece, slab k+3) is issued BETWEEN the MFMAs of MFMA(k) instead of in LOAD(k): the
+// LOAD segment shrinks to the fragment reads and the waits, so it hides under the other group's MFMA segment; the prefetch
+// distance grows to 3 k-steps (a slab is re-targeted in the MFMA segment after the phase that last read it has retired
+// its reads), and the wait that closes LOAD(k) leaves exactly MFMA(k-1)'s DMA in flight.
+template <typename TT, int MI, int WM, int NHP, int KS, bool DS, bool IM = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
   static_assert(!(DS && KS == 2), "the fused shortcut is built for the pixel-split layouts only");
+  static_assert(!(DS && IM), "the fused shortcut keeps its DMA in the LOAD segments");
   constexpr int NI = 4, WN = KS == 2 ? 2 : 8 / WM;
   constexpr int CAP = WM * MI * 16;                          // pixels a tile can hold (KS = 1)
   constexpr int NGP = DS ? (CAP / 16 + 7) / 8 : 0;           // gather pieces per wave and shortcut image
@@ -221,6 +227,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
   for (int j = 0; j < NHP; ++j) issue_halo(0, j);
   issue_slab(0, 0, 0);
   issue_slab(0, 1, 1);
+  if (IM) issue_slab(0, 2, 2);
 
   // fragment addressing
   int A[MI];  // (pixel index in the halo image) * 64 + k-group * 16, before the tap offset and the swizzle
@@ -267,26 +274,57 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
         }
       }
       constexpr bool HP = t >= 1 && t <= NHP;   // (no halo DMA at tap 0: the other group may still be reading that buffer's last tap)
-      if (HP) issue_halo(ci + 1, t - 1);
-      // DS: shortcut image 1 rides in the idle taps NHP+1.. of the LAST main chunk (other chunks: dummy copies, so that
-      // the DMA count per phase - and with it every s_waitcnt immediate - is the same in every chunk)
-      constexpr int XE = (DS && t > NHP) ? ((t - NHP - 1) * PPT < NGP ? (NGP - (t - NHP - 1) * PPT < PPT ? NGP - (t - NHP - 1) * PPT : PPT) : 0) : 0;
+      if (!IM) {
+        if (HP) issue_halo(ci + 1, t - 1);
+        // DS: shortcut image 1 rides in the idle taps NHP+1.. of the LAST main chunk (other chunks: dummy copies, so that
+        // the DMA count per phase - and with it every s_waitcnt immediate - is the same in every chunk)
+        constexpr int XE = (DS && t > NHP) ? ((t - NHP - 1) * PPT < NGP ? (NGP - (t - NHP - 1) * PPT < PPT ? NGP - (t - NHP - 1) * PPT : PPT) : 0) : 0;
 #pragma unroll
-      for (int e = 0; e < XE; ++e) {
-        if (ci == nch - 1) issue_gather(1, (t - NHP - 1) * PPT + e);
-        else pp_dma16((const char*)g_pp_zero, lds0 + 2 * HB + RING * WB + wave * 1024 + ((t - NHP - 1) * PPT + e) * 8192);
+        for (int e = 0; e < XE; ++e) {
+          if (ci == nch - 1) issue_gather(1, (t - NHP - 1) * PPT + e);
+          else pp_dma16((const char*)g_pp_zero, lds0 + 2 * HB + RING * WB + wave * 1024 + ((t - NHP - 1) * PPT + e) * 8192);
+        }
+        issue_slab(t + 2 < TAPS ? ci : ci + 1, (t + 2) % TAPS, (k + 2) & (RING - 1));
+        pp_wait_vm<NWI + (HP ? 1 : 0) + XE>();  // everything older than this phase's DMA has landed (slab k+1; next halo by t = 8)
+        if (DS && t == TAPS - 1) pp_wait_lgkm0();  // (the first shortcut phase re-targets this chunk's halo buffer: retire its reads here)
+      } else {
+        // only the DMA issued in the previous phase's MFMA segment may still be in flight (slab k+2; slab k+1 has landed)
+        constexpr int tp = (t + TAPS - 1) % TAPS;
+        pp_wait_vm<NWI + ((tp >= 1 && tp <= NHP) ? 1 : 0)>();
       }
-      issue_slab(t + 2 < TAPS ? ci : ci + 1, (t + 2) % TAPS, (k + 2) & (RING - 1));
-      pp_wait_vm<NWI + (HP ? 1 : 0) + XE>();  // everything older than this phase's DMA has landed (slab k+1; next halo by t = 8)
-      if (DS && t == TAPS - 1) pp_wait_lgkm0();  // (the first shortcut phase re-targets this chunk's halo buffer: retire its reads here)
       pp_barrier();
       // ---------------- MFMA(k)
       pp_wait_lgkm0();
       __builtin_amdgcn_sched_barrier(0);
+      if (!IM) {
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = TT::mfma(wf[ni], pf[mi], acc[mi][ni]);
+          for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = TT::mfma(wf[ni], pf[mi], acc[mi][ni]);
+      } else {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            acc[mi][ni] = TT::mfma(wf[ni], pf[mi], acc[mi][ni]);
+            constexpr int HPOS = 3, S0POS = MI + 3, S1POS = 2 * MI + 3;   // after which MFMAs the DMA instructions go
+            const int idx = ni * MI + mi;
+            if ((idx == HPOS && HP) || idx == S0POS || (idx == S1POS && NWI == 2)) {
+              __builtin_amdgcn_sched_barrier(0);
+              if (idx == HPOS) issue_halo(ci + 1, t - 1);
+              else {
+                const int ci3 = t + 3 < TAPS ? ci : ci + 1;
+                const int cc = ci3 < nch ? ci3 : nch - 1;
+                const int chunk = KS == 2 ? grp + 2 * cc : cc;
+                const char* sp = wsrc + (size_t)(chunk * TAPS + (ci3 < nch ? (t + 3) % TAPS : TAPS - 1)) * 4096;
+                const unsigned dp = wdst + (unsigned)((k + 3) & (RING - 1)) * WB;
+                if (idx == S0POS) pp_dma16(sp, dp);
+                else pp_dma16(sp + 1024, dp + 1024);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+      }
       pp_barrier();
     });
   }
@@ -557,9 +595,18 @@ extern "C" int frmap_conv_pp_tuning(int enable, int tile_px, int bn) {
   return 0;
 }
 
+static int g_pp_im = -1;   // -1: environment FRMAP_PP_IM (default 0: measured 4-6 % SLOWER than issuing the DMA in the LOAD segments)
+extern "C" int frmap_conv_pp_im(int v) { g_pp_im = v; return 0; }
+
 template <typename TT, int MI, int WM, int NHP, int KS, bool DS = false>
 static int pp_launch(const PPParams& p, hipStream_t st) {
-  auto kern = conv3x3_pp_kernel<TT, MI, WM, NHP, KS, DS>;
+  static int im_env = -1;
+  if (im_env < 0) im_env = pp_env("FRMAP_PP_IM", 0);
+  const bool im = !DS && (g_pp_im >= 0 ? g_pp_im : im_env) != 0;
+  typedef void (*kern_t)(const PPParams);
+  kern_t kern;
+  if constexpr (DS) kern = conv3x3_pp_kernel<TT, MI, WM, NHP, KS, true, false>;
+  else kern = im ? (kern_t)conv3x3_pp_kernel<TT, MI, WM, NHP, KS, false, true> : (kern_t)conv3x3_pp_kernel<TT, MI, WM, NHP, KS, false, false>;
   if (frmap_big_lds((const void*)kern, 160 * 1024)) return -2;
   const int wb = (KS == 2 ? 2 : 8 / WM) * 64 * 64;
   int lds = KS * (2 * NHP * (8 / KS) * 1024 + 4 * wb) + (DS ? ((WM * MI + 7) / 8) * 8192 : 0);

@@ -9,11 +9,15 @@ def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=256); ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--pp", type=int, default=1); ap.add_argument("--tile-px", type=int, default=-1); ap.add_argument("--bn", type=int, default=-1)
     ap.add_argument("--relu-data", type=int, default=1, help="1: non-negative half-sparse activations (post-ReLU statistics), 0: N(0,1)")
-    ap.add_argument("--res", type=int, default=0); ap.add_argument("--variants", default="0,-1,256,128,1282")
+    ap.add_argument("--res", type=int, default=0); ap.add_argument("--variants", default="0,-1:0,-1:1")
     a = ap.parse_args()
     lib = _lib.load()
     dev, dt = "cuda", torch.bfloat16
-    variants = [int(v) for v in a.variants.split(",")]   # channel-tile settings to compare: -1 heuristic, 128, 256, 1282 (split-K), 0 = first generation
+    # settings to compare, "bn[:im]": bn = -1 heuristic, 128, 256, 1282 (split-K), 0 = first generation; im = 1 / 0: DMA issued in
+    # the MFMA segments (default) / in the LOAD segments
+    variants = [(int(v.split(":")[0]), int(v.split(":")[1]) if ":" in v else -1) for v in a.variants.split(",")]
+    import ctypes
+    raw = ctypes.CDLL(_lib.LIB_PATH)
     for name, H, C in (("l2 28x28 128", 28, 128), ("l3 14x14 256", 14, 256), ("l4 7x7 512", 7, 512)):
         x = torch.randn(a.batch, H, H, C, device=dev)
         if a.relu_data: x = torch.relu(x)
@@ -25,14 +29,15 @@ def main():
         res = {v: [] for v in variants}
         for rnd in range(4):           # interleaved rounds in one process (variants compared on the same device / clocks)
             for v in variants:
-                lib.frmap_conv_pp_tuning(a.pp if v != 0 else 0, a.tile_px, v)
+                lib.frmap_conv_pp_tuning(a.pp if v[0] != 0 else 0, a.tile_px, v[0])
+                raw.frmap_conv_pp_im(v[1])
                 for _ in range(3): ops.conv_igemm(x, w, sh, C, 3, 1, 1, True, r)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(a.reps): ops.conv_igemm(x, w, sh, C, 3, 1, 1, True, r)
                 e1.record(); torch.cuda.synchronize()
                 res[v].append(e0.elapsed_time(e1) / a.reps * 1e3)
-        print(f"{name:16s} " + "  ".join(f"bn{v}: {min(t):6.1f} us ({fl / min(t) / 1e6:5.0f} TF)" for v, t in res.items()), flush=True)
+        print(f"{name:16s} " + "  ".join(f"bn{v[0]}/im{v[1]}: {min(t):6.1f} us ({fl / min(t) / 1e6:5.0f} TF)" for v, t in res.items()), flush=True)
 
 if __name__ == "__main__":
     main()
