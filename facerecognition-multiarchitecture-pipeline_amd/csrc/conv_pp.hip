@@ -251,7 +251,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
   pp_barrier();
   if (grp == 1) pp_barrier();  // group B runs one barrier behind group A from here on
 
-  for (int ci = 0; ci < nch; ++ci) {
+  // one chunk = nine phases.  LAST (DS only): the chunk before the shortcut phases - its idle DMA slots carry shortcut
+  // images 0 and 1 (a separate instantiation of the body, so that the other chunks issue no DMA for the shortcut at all)
+  auto chunk_body = [&](int ci, auto last_c) {
+    constexpr bool LAST = decltype(last_c)::value;
     const char* hb = halo + (ci & 1) * HB;
     if (DS) {   // the shortcut variant is short of registers: recompute the 63 per-tap fragment addresses (3 VALU each)
 #pragma unroll  // instead of letting the compiler keep them live across the loop
@@ -276,17 +279,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
       constexpr bool HP = t >= 1 && t <= NHP;   // (no halo DMA at tap 0: the other group may still be reading that buffer's last tap)
       if (!IM) {
         if (HP) issue_halo(ci + 1, t - 1);
-        // DS: shortcut image 1 rides in the idle taps NHP+1.. of the LAST main chunk (other chunks: dummy copies, so that
-        // the DMA count per phase - and with it every s_waitcnt immediate - is the same in every chunk)
-        constexpr int XE = (DS && t > NHP) ? ((t - NHP - 1) * PPT < NGP ? (NGP - (t - NHP - 1) * PPT < PPT ? NGP - (t - NHP - 1) * PPT : PPT) : 0) : 0;
+        // DS: shortcut image 1 rides in the idle taps NHP+1.. of the LAST main chunk (image 0 in its halo slots)
+        constexpr int XE = (DS && LAST && t > NHP) ? ((t - NHP - 1) * PPT < NGP ? (NGP - (t - NHP - 1) * PPT < PPT ? NGP - (t - NHP - 1) * PPT : PPT) : 0) : 0;
 #pragma unroll
-        for (int e = 0; e < XE; ++e) {
-          if (ci == nch - 1) issue_gather(1, (t - NHP - 1) * PPT + e);
-          else pp_dma16((const char*)g_pp_zero, lds0 + 2 * HB + RING * WB + wave * 1024 + ((t - NHP - 1) * PPT + e) * 8192);
-        }
+        for (int e = 0; e < XE; ++e) issue_gather(1, (t - NHP - 1) * PPT + e);
         issue_slab(t + 2 < TAPS ? ci : ci + 1, (t + 2) % TAPS, (k + 2) & (RING - 1));
         pp_wait_vm<NWI + (HP ? 1 : 0) + XE>();  // everything older than this phase's DMA has landed (slab k+1; next halo by t = 8)
-        if (DS && t == TAPS - 1) pp_wait_lgkm0();  // (the first shortcut phase re-targets this chunk's halo buffer: retire its reads here)
+        if (DS && LAST && t == TAPS - 1) pp_wait_lgkm0();  // (the first shortcut phase re-targets this chunk's halo buffer: retire its reads here)
       } else {
         // only the DMA issued in the previous phase's MFMA segment may still be in flight (slab k+2; slab k+1 has landed)
         constexpr int tp = (t + TAPS - 1) % TAPS;
@@ -327,6 +326,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
       }
       pp_barrier();
     });
+  };
+  if (DS) {
+    for (int ci = 0; ci + 1 < nch; ++ci) chunk_body(ci, std::false_type{});
+    chunk_body(nch - 1, std::true_type{});
+  } else {
+    for (int ci = 0; ci < nch; ++ci) chunk_body(ci, std::false_type{});
   }
   if (DS) {
     // ---------------- shortcut phases: one 32-channel one-tap k-step each (k = nk + d)
@@ -585,7 +590,8 @@ static int pp_env(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 // run-time overrides (frmap_conv_pp_tuning): -1 = not set (environment / heuristic decides)
-static int g_pp_on = -1, g_pp_px = -1, g_pp_bn = -1, g_pp_ks = -1;
+static int g_pp_on = -1, g_pp_px = -1, g_pp_bn = -1, g_pp_ks = -1, g_pp_ds = -1;
+extern "C" int frmap_conv_pp_ds(int v) { g_pp_ds = v; return 0; }   // A/B hook: fused-shortcut form on (1) / off (0)
 
 extern "C" int frmap_conv_pp_tuning(int enable, int tile_px, int bn) {
   g_pp_on = enable;
@@ -651,11 +657,11 @@ int frmap_conv3x3_pp(const void* in, const void* w_packed, const float* shift, c
     if (residual || ds->Cin <= 0 || ds->Cin % 32 || ds->stride < 1 || (ds->Hi - 1) / ds->stride + 1 != Hi ||
         (ds->Wi - 1) / ds->stride + 1 != Wi || (long long)B * ds->Hi * ds->Wi * ds->Cin * 2 >= (1ll << 46))
       return 0;
-    // A/B switch, OFF by default: parity-green, but end to end it only ties the first-generation fused kernel (layers 2 / 3
-    // at 256 faces: 71 us vs 71 us per launch) - the dummy DMA slots it adds to every main chunk and the recomputed
-    // fragment addresses lengthen the LOAD segments by about what the faster MFMA phases save
+    // A/B switch FRMAP_CONV_PP_DS (on): with the last main chunk peeled (no shortcut DMA in the other chunks) the fused form
+    // runs 64.8 / 52.9 us at 28x28 / 14x14 (256 faces) against the first generation's 72.4 / 68.4
     static int ds_on = -1;
-    if (ds_on < 0) ds_on = pp_env("FRMAP_CONV_PP_DS", 0);
+    if (ds_on < 0) ds_on = pp_env("FRMAP_CONV_PP_DS", 1);
+    if (g_pp_ds >= 0) ds_on = g_pp_ds;
     if (!ds_on && g_pp_on < 0) return 0;
     p.ds_in = ds->in; p.ds_w = ds->w; p.ds_Hi = ds->Hi; p.ds_Wi = ds->Wi; p.ds_Cin = ds->Cin; p.ds_stride = ds->stride;
     p.dsc = ds->Cin / 32;
