@@ -237,15 +237,38 @@ def instrument(ops, torch, dt):
 
 
 def stored_traffic():
-    """HBM bytes per launch per kernel from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE runs
-    of `bench.py --graph 0 --streams 1`, FETCH_SIZE doubled per the gfx950 correction)."""
+    """HBM traffic per bench-label from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE runs of
+    `bench.py --graph 0 --streams 1`, FETCH_SIZE doubled per the gfx950 correction).  The profile is keyed by the full
+    template instantiation (e.g. `conv3x3_pp_kernel<BF16, 7, 2, 3, 1, false, false>`); a bench label such as
+    `conv3x3_pp_kernel<BF16>` covers several of them, so the lookup returns, per label, the average HBM bytes per
+    LAUNCH over the instantiations it covers, weighted by how often each was launched in the profiled run."""
     for name in (TRAFFIC_PROFILE, "r01_hbm_traffic_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                return name, {k: v["hbm_bytes_per_launch"] for k, v in json.load(f)["kernels"].items()}
+                kernels = json.load(f)["kernels"]
         except Exception:
             continue
-    return None, {}
+
+        def lookup(label):
+            if label in kernels:
+                return kernels[label]["hbm_bytes_per_launch"]
+            head = label[:-1] + "," if label.endswith(">") else label      # "kernel<BF16>" -> "kernel<BF16,"
+            want_ds = None
+            if label.startswith("conv3x3_pp_kernel"):
+                want_ds = ", DS>" in label
+                head = label.split(",")[0].rstrip(">") + ","
+            tot = n = 0
+            for k, v in kernels.items():
+                if not k.startswith(head):
+                    continue
+                if want_ds is not None and k.startswith("conv3x3_pp_kernel<") and (k.rstrip(">").split(", ")[-2] == "true") != want_ds:
+                    continue
+                c = max(v.get("launches_FETCH_SIZE", 0), 1)
+                tot += v["hbm_bytes_per_launch"] * c
+                n += c
+            return int(tot / n) if n else None
+        return name, lookup
+    return None, (lambda label: None)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -452,7 +475,7 @@ def worker(args) -> int:
             roof_us = max(flop / (MFMA_PEAK_TFLOPS * 1e12), nbytes / (HBM_PEAK_GBS * 1e9)) * 1e6
             roof_total += roof_us
             meas_total += us
-            pm = pmc.get(kname)
+            pm = pmc(kname)
             layerwise.append({"kernel": kname, "launches_per_step": n, "flop": flop, "bytes": nbytes, "us": round(us, 2),
                               "roof_us": round(roof_us, 2), "bound": "mfma" if flop / (MFMA_PEAK_TFLOPS * 1e12) >= nbytes / (HBM_PEAK_GBS * 1e9) else "hbm",
                               "tflops": round(flop / us / 1e6, 1) if us > 0 else None, "gbs": round(nbytes / us / 1e3, 1) if us > 0 else None,
@@ -468,7 +491,7 @@ def worker(args) -> int:
                 bound, achieved, peak, unit = "hbm", dom["bytes"] / dom["us"] / 1e3, HBM_PEAK_GBS, "GB/s"
             roofline = {"bound": bound, "kernel": dom_name, "achieved": round(achieved, 2), "peak": peak,
                         "unit": unit, "frac": round(achieved / peak, 4),
-                        "traffic": pmc.get(dom_name), "traffic_source": {"stored": f"profiles/{prof_name}"} if prof_name else None,
+                        "traffic": pmc(dom_name), "traffic_source": {"stored": f"profiles/{prof_name}"} if prof_name else None,
                         "measured": "standalone eager launches at the full per-GPU batch, one stream (instrumented pass, HIP events)",
                         "launches_per_step": dom["launches"] // NREP, "avg_launch_us": round(dom["us"] / dom["launches"], 2),
                         "flop_per_launch": dom["flop"] / dom["launches"],

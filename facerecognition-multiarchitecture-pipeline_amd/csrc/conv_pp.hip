@@ -590,7 +590,8 @@ static int pp_env(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 // run-time overrides (frmap_conv_pp_tuning): -1 = not set (environment / heuristic decides)
-static int g_pp_on = -1, g_pp_px = -1, g_pp_bn = -1, g_pp_ks = -1, g_pp_ds = -1;
+static int g_pp_on = -1, g_pp_px = -1, g_pp_bn = -1, g_pp_ks = -1, g_pp_ds = -1, g_pp_pitch = -1;
+extern "C" int frmap_conv_pp_pitch(int v) { g_pp_pitch = v; return 0; }   // A/B hook: conflict-free halo pitch on (1) / off (0)
 extern "C" int frmap_conv_pp_ds(int v) { g_pp_ds = v; return 0; }   // A/B hook: fused-shortcut form on (1) / off (0)
 
 extern "C" int frmap_conv_pp_tuning(int enable, int tile_px, int bn) {
@@ -648,6 +649,13 @@ int frmap_conv3x3_pp(const void* in, const void* w_packed, const float* shift, c
   p.in = in; p.wpk = w_packed; p.shift = shift; p.res = residual; p.out = out;
   p.N = B; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
   p.M = (int)Mll; p.HoWo = Hi * Wi; p.Hp = Hi + 2; p.Wp = Wi + 2;
+  // LDS pitch of a halo row (pixels).  A 16-pixel MFMA fragment that wraps an output row continues Wp - Wi + 1 pixels
+  // further on; with Wp = Wi (mod 8) that keeps the fragment's 16-byte slots on distinct banks (the swizzle repeats every 8
+  // pixels).  Columns past Wi + 1 are just more zero padding for the DMA.  (A/B: FRMAP_PP_PITCH)
+  static int pitch_env = -1;
+  if (pitch_env < 0) pitch_env = pp_env("FRMAP_PP_PITCH", 0);
+  const bool wide_pitch = (g_pp_pitch >= 0 ? g_pp_pitch : pitch_env) != 0;
+  if (wide_pitch) { while (p.Wp % 8 != Wi % 8) ++p.Wp; }
   p.magic_Wp = frmap_magic((uint32_t)p.Wp); p.magic_Hp = frmap_magic((uint32_t)p.Hp);
   p.dHoWo = frmap_div_make((uint32_t)p.HoWo); p.dWo = frmap_div_make((uint32_t)Wi);
   p.nchunks = Cin / 32;

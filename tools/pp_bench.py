@@ -16,7 +16,7 @@ def main():
     dev, dt = "cuda", torch.bfloat16
     # settings to compare, "bn[:im]": bn = -1 heuristic, 128, 256, 1282 (split-K), 0 = first generation; im = 1 / 0: DMA issued in
     # the MFMA segments (default) / in the LOAD segments
-    variants = [(int(v.split(":")[0]), int(v.split(":")[1]) if ":" in v else -1) for v in a.variants.split(",")]
+    variants = [(int(v.split(":")[0]), int(v.split(":")[1]) if ":" in v else -1, int(v.split(":")[2]) if v.count(":") > 1 else -1) for v in a.variants.split(",")]
     import ctypes
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name, H, C in (("l2 28x28 128", 28, 128), ("l3 14x14 256", 14, 256), ("l4 7x7 512", 7, 512)):
@@ -39,13 +39,14 @@ def main():
             for v in variants:
                 lib.frmap_conv_pp_tuning(a.pp if v[0] != 0 else 0, a.tile_px, v[0])
                 raw.frmap_conv_pp_im(v[1])
+                raw.frmap_conv_pp_pitch(v[2])
                 for _ in range(3): run()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(a.reps): run()
                 e1.record(); torch.cuda.synchronize()
                 res[v].append(e0.elapsed_time(e1) / a.reps * 1e3)
-        print(f"{name:16s} " + "  ".join(f"bn{v[0]}/im{v[1]}: {min(t):6.1f} us ({fl / min(t) / 1e6:5.0f} TF)" for v, t in res.items()), flush=True)
+        print(f"{name:16s} " + "  ".join(f"bn{v[0]}/im{v[1]}/pitch{v[2]}: {min(t):6.1f} us ({fl / min(t) / 1e6:5.0f} TF)" for v, t in res.items()), flush=True)
 
 if __name__ == "__main__":
     main()
