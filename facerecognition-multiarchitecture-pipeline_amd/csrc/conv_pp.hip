@@ -28,6 +28,9 @@
 #include "frmap_common.h"
 #include <stdlib.h>
 
+#include <array>
+#include <map>
+#include <mutex>
 #include <utility>
 
 struct PPParams {
@@ -572,6 +575,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3s2_pp_kernel(const PPParams p) 
 // output row, + extra (s1: 3 = one row above, one below; s2 half-resolution maps: 2) - evaluated exactly as the kernels
 // do, over one period of the tile start positions
 static int pp_max_rows(long long M, int tile_px, int howo, int wo, int hp, int extra) {
+  // (memoised: the planner runs on every launch, the scan is up to one image's worth of tile starts)
+  static std::mutex mu;
+  static std::map<std::array<long long, 6>, int> memo;
+  const std::array<long long, 6> key = {M, tile_px, howo, wo, hp, extra};
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = memo.find(key);
+    if (it != memo.end()) return it->second;
+  }
   int best = 0;
   const long long mtiles = (M + tile_px - 1) / tile_px;
   const long long lim = mtiles < howo ? mtiles : howo;
@@ -581,6 +593,11 @@ static int pp_max_rows(long long M, int tile_px, int howo, int wo, int hp, int e
     const int oy0 = (int)((m0 - n0 * howo) / wo), oy1 = (int)((mend - n1 * howo) / wo);
     const int rows = (int)(n1 - n0) * hp + oy1 - oy0 + extra;
     if (rows > best) best = rows;
+  }
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    if (memo.size() > 4096) memo.clear();
+    memo[key] = best;
   }
   return best;
 }
