@@ -29,6 +29,9 @@ PROTOTYPES = {
     "frmap_small_cin_kpad": (_i, [_i, _i]),
     "frmap_pack_conv_weight_c3": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "frmap_conv_small_cin": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "frmap_conv_small_cin_pool2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "frmap_conv_igemm_pool2_supported": (_i, [_i, _i, _i, _i, _i]),
+    "frmap_conv_igemm_pool2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "frmap_stem7x7_maxpool": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "frmap_stem7x7_maxpool2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "frmap_stem7x7_maxpool_u8": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

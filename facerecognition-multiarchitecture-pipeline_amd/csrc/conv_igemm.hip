@@ -22,6 +22,7 @@
 //            slab is a straight 36 KB copy done with global_load_lds_dwordx4 (no VGPRs).
 #include "frmap_common.h"
 #include <stdlib.h>
+#include <string.h>
 
 struct ConvParams {
   const void* in;
@@ -44,6 +45,7 @@ struct ConvParams {
   const void* ds_in;   // [N][ds_Hi][ds_Wi][ds_Cin]
   const void* ds_w;    // packed like a 1x1 conv: [Cout/64][ds_Cin/32][1][64][4][8]
   int ds_Hi, ds_Wi, ds_Cin, ds_stride, ds_chunks;
+  FrmapPoolOrder pool;  // conv_igemm_kernel<..., POOL = true>: pool-major pixel order of the fused 2x2 max-pool
 };
 
 // 64 zero bytes: out-of-image (padding) pixels LOAD from here instead of branching around the load —
@@ -61,7 +63,9 @@ __device__ __forceinline__ int px_off(int q, int slot) {
   return ((q >> 2) << 8) + (((((q & 3) << 2) | slot) ^ (((q >> 2) & 3) << 1)) << 4);
 }
 
-template <typename TT, int BM, int KS, int SWZ>
+// POOL = true (3x3 stride 1 only): pixels are enumerated in pool-major order (frmap_pool_coords) and the epilogue writes
+// the 2x2-max-pooled map [N][Ho/2][Wo/2][Cout] instead of the conv output.
+template <typename TT, int BM, int KS, int SWZ, bool POOL = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
   constexpr int MI = BM / 64;
   constexpr int NI = 4;
@@ -95,7 +99,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 
   // origin of this tile in the "virtual padded row stack": padded row index G = n*Hp + iy + pad.
   int n0 = 0, rr0 = 0, nrows = 0;
-  if (KS > 1) {
+  if (POOL) {  // first pixel = top-left of the first window, last pixel = bottom-right of the last one
+    int oy0, ox0, n1, oy1, ox1;
+    frmap_pool_coords(m0, p.pool, n0, oy0, ox0);
+    frmap_pool_coords(mlast, p.pool, n1, oy1, ox1);
+    rr0 = oy0;
+    nrows = (n1 - n0) * p.Hp + oy1 - rr0 + KS;
+  } else if (KS > 1) {
     n0 = frmap_div(m0, p.dHoWo);
     const int oy0 = frmap_div(m0 - n0 * p.HoWo, p.dWo);
     rr0 = oy0 * p.stride;
@@ -112,6 +122,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     int qb;
     if (KS == 1) {
       qb = m - m0;
+    } else if (POOL) {
+      int n, oy, ox;
+      frmap_pool_coords(m, p.pool, n, oy, ox);
+      qb = ((n - n0) * p.Hp + oy - rr0) * p.Wp + ox;
     } else {
       const int n = frmap_div(m, p.dHoWo);
       const int rem = m - n * p.HoWo;
@@ -227,7 +241,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 
   // ---- epilogue: + shift (+ residual) (ReLU) -> NHWC, whole-line 16-byte stores via an LDS transpose
   __syncthreads();  // every wave is done reading the staged tiles; LDS is free for the transpose
-  if (p.ksplit > 1)
+  if (POOL)
+    conv_epilogue_pool2<TT, MI, NI>(acc, smem + wave * (16 * (NI * 64 + 16)), (m0 + wave * (BM / 4)) >> 2, p.M >> 2, p.Cout,
+                                    nt << 6, p.shift, (typename TT::elem*)p.out, p.relu, lane);
+  else if (p.ksplit > 1)
     conv_epilogue_partial<MI, NI>(acc, smem + wave * (16 * (NI * 64 + 16)), m0 + wave * (BM / 4), p.M, p.Cout, nt << 6,
                                   p.slab + (size_t)kslice * p.M * p.Cout, lane);
   else
@@ -1071,9 +1088,9 @@ static int halo_rows_bound(int BM, int Ho, int Wo, int Hp, int stride, int KS) {
   return gdiff + KS;
 }
 
-template <typename TT, int BM, int KS, int SWZ>
+template <typename TT, int BM, int KS, int SWZ, bool POOL = false>
 static int launch(const ConvParams& p, int lds_bytes, hipStream_t st) {
-  auto kern = conv_igemm_kernel<TT, BM, KS, SWZ>;
+  auto kern = conv_igemm_kernel<TT, BM, KS, SWZ, POOL>;
   if (frmap_big_lds((const void*)kern, 160 * 1024)) return -2;
   const int scratch = 4 * 16 * (4 * 64 + 16);  // epilogue transpose region (4 waves)
   if (lds_bytes < scratch) lds_bytes = scratch;
@@ -1292,6 +1309,61 @@ extern "C" int frmap_conv_igemm_ds(const void* in, const void* w_packed, const f
   FRMAP_REQUIRE(ds_in && ds_w_packed, "conv_igemm_ds: null shortcut pointer");
   const DsArgs d = {ds_in, ds_w_packed, ds_Hi, ds_Wi, ds_Cin, ds_stride};
   return conv_igemm_impl(in, w_packed, shift, nullptr, out, B, Hi, Wi, Cin, Cout, 3, 1, 1, relu, dtype, d, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv3x3 s1 p1 + shift (+ReLU) + MaxPool2d(2, 2) in one launch (face_models.py:38-40: BaselineNet's
+// `self.pool(F.relu(self.bnK(self.convK(x))))`; :121-141: SiameseNet's conv -> BN -> ReLU -> MaxPool2d(2)).  The conv
+// map never reaches HBM: out = [B][Hi/2][Wi/2][Cout].
+// ------------------------------------------------------------------------------------------------
+static int pool_rows_bound(int BM, int Ho, int Wo, int Hp) {
+  const int nw = BM / 4, Wo2 = Wo / 2, Win = (Ho / 2) * Wo2;
+  const int pairs = (nw + Wo2 - 2) / Wo2 + 1;      // window rows BM/4 consecutive windows can touch
+  const int cross = (nw + Win - 2) / Win;          // image crossings (each adds the Hp - Ho = 2 padding rows)
+  const int x = cross < pairs - 1 ? cross : pairs - 1;
+  return 2 * pairs + 2 * x + 2;
+}
+
+extern "C" int frmap_conv_igemm_pool2_supported(int B, int Hi, int Wi, int Cin, int Cout) {
+  if (B <= 0 || Hi <= 0 || Wi <= 0 || Hi % 2 || Wi % 2 || Cin <= 0 || Cin % 32 || Cout <= 0 || Cout % 64) return 0;
+  if ((long long)B * Hi * Wi >= (1ll << 31) || Wi + 2 >= 32768 || Hi + 2 >= 32768) return 0;
+  const long long hb = (long long)pool_rows_bound(128, Hi, Wi, Hi + 2) * (Wi + 2) * 64;
+  return hb + 9 * 4096 <= 160 * 1024 && hb / 64 < 65536;
+}
+
+extern "C" int frmap_conv_igemm_pool2(const void* in, const void* w_packed, const float* shift, void* out, int B, int Hi,
+                                      int Wi, int Cin, int Cout, int relu, int dtype, void* stream) {
+  FRMAP_REQUIRE(in && w_packed && shift && out, "conv_igemm_pool2: null pointer");
+  FRMAP_REQUIRE(dtype == FRMAP_BF16 || dtype == FRMAP_F16, "conv_igemm_pool2: bad dtype %d", dtype);
+  FRMAP_REQUIRE(relu == 0 || relu == 1, "conv_igemm_pool2: activation %d does not commute with the max", relu);
+  FRMAP_REQUIRE(frmap_conv_igemm_pool2_supported(B, Hi, Wi, Cin, Cout),
+                "conv_igemm_pool2: shape B=%d %dx%d Cin=%d Cout=%d not taken (even H and W, Cin %% 32 == 0, Cout %% 64 == 0, rows fit LDS)",
+                B, Hi, Wi, Cin, Cout);
+  ConvParams p;
+  memset(&p, 0, sizeof(p));
+  p.in = in; p.wpk = w_packed; p.shift = shift; p.res = nullptr; p.out = out;
+  p.N = B; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Hi; p.Wo = Wi; p.Cout = Cout;
+  p.stride = 1; p.pad = 1; p.relu = relu;
+  p.M = B * Hi * Wi; p.HoWo = Hi * Wi; p.Hp = Hi + 2; p.Wp = Wi + 2;
+  p.magic_Wp = frmap_magic((uint32_t)p.Wp); p.magic_Hp = frmap_magic((uint32_t)p.Hp);
+  p.dHoWo = frmap_div_make((uint32_t)p.HoWo); p.dWo = frmap_div_make((uint32_t)p.Wo);
+  p.nchunks = Cin / 32; p.ksplit = 1; p.slab = nullptr; p.dbg = 0;
+  p.pool.Wo2 = Wi / 2; p.pool.Win = (Hi / 2) * (Wi / 2);
+  p.pool.dWo2 = frmap_div_make((uint32_t)p.pool.Wo2); p.pool.dWin = frmap_div_make((uint32_t)p.pool.Win);
+  const int wbytes = 9 * 4096, ntiles = Cout / 64;
+  int BM = 256;
+  long long hb = (long long)pool_rows_bound(256, Hi, Wi, p.Hp) * p.Wp * 64;
+  if (hb + wbytes > 80 * 1024) {   // two workgroups per CU when the smaller tile allows it
+    BM = 128;
+    hb = (long long)pool_rows_bound(128, Hi, Wi, p.Hp) * p.Wp * 64;
+  }
+  hb = (hb + 1023) & ~1023ll;
+  p.halo_bytes = (int)hb;
+  p.nblocks = ((p.M + BM - 1) / BM) * ntiles;
+  const int lds = p.halo_bytes + wbytes;
+  hipStream_t st = (hipStream_t)stream;
+  if (BM == 256) return dtype == FRMAP_BF16 ? launch<BF16, 256, 3, 1, true>(p, lds, st) : launch<F16, 256, 3, 1, true>(p, lds, st);
+  return dtype == FRMAP_BF16 ? launch<BF16, 128, 3, 1, true>(p, lds, st) : launch<F16, 128, 3, 1, true>(p, lds, st);
 }
 
 // ------------------------------------------------------------------------------------------------

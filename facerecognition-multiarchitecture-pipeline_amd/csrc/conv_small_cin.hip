@@ -10,6 +10,7 @@
 // 16-byte LDS read of a lane is 2 neighbouring input pixels.  K = 224 (7 k-steps of 32) for the
 // 7x7 stem, 64 (2 k-steps) for the 3x3 first layer.  Same tiling as conv_igemm.hip otherwise.
 #include "frmap_common.h"
+#include <string.h>
 
 struct SmallCinParams {
   const void* in;
@@ -22,9 +23,11 @@ struct SmallCinParams {
   uint32_t magic_Wl2, magic_Hp;
   int halo_bytes;
   int nblocks;
+  FrmapPoolOrder pool;  // POOL = true: pool-major pixel order of the fused 2x2 max-pool
 };
 
-template <typename TT, int NI, int KH, int KW, int STRIDE>
+// POOL = true (stride 1): pool-major pixel order, the epilogue writes the 2x2-max-pooled map (conv_epilogue_pool2).
+template <typename TT, int NI, int KH, int KW, int STRIDE, bool POOL = false>
 __global__ __launch_bounds__(256, 2) void conv_small_cin_kernel(const SmallCinParams p) {
   constexpr int BM = 256, MI = 4;
   constexpr int KR = (KW * 4 > 16) ? 32 : 16;
@@ -45,11 +48,18 @@ __global__ __launch_bounds__(256, 2) void conv_small_cin_kernel(const SmallCinPa
   const int m0 = blockIdx.x * BM;
   const int mlast = min(m0 + BM, p.M) - 1;
 
-  const int n0 = m0 / p.HoWo;
-  const int oy0 = (m0 - n0 * p.HoWo) / p.Wo;
+  int n0, oy0, n1, oy1;
+  if (POOL) {
+    int ox;
+    frmap_pool_coords(m0, p.pool, n0, oy0, ox);
+    frmap_pool_coords(mlast, p.pool, n1, oy1, ox);
+  } else {
+    n0 = m0 / p.HoWo;
+    oy0 = (m0 - n0 * p.HoWo) / p.Wo;
+    n1 = mlast / p.HoWo;
+    oy1 = (mlast - n1 * p.HoWo) / p.Wo;
+  }
   const int rr0 = oy0 * STRIDE;
-  const int n1 = mlast / p.HoWo;
-  const int oy1 = (mlast - n1 * p.HoWo) / p.Wo;
   const int nrows = (n1 - n0) * p.Hp + oy1 * STRIDE - rr0 + KH;
 
   // ---- stage weights (whole [COUT][KPAD+8] image, already in this order in global) -------------
@@ -102,10 +112,15 @@ __global__ __launch_bounds__(256, 2) void conv_small_cin_kernel(const SmallCinPa
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = min(m0 + wave * 64 + mi * 16 + lr, p.M - 1);
-    const int n = m / p.HoWo;
-    const int rem = m - n * p.HoWo;
-    const int oy = rem / p.Wo;
-    const int ox = rem - oy * p.Wo;
+    int n, oy, ox;
+    if (POOL) {
+      frmap_pool_coords(m, p.pool, n, oy, ox);
+    } else {
+      n = m / p.HoWo;
+      const int rem = m - n * p.HoWo;
+      oy = rem / p.Wo;
+      ox = rem - oy * p.Wo;
+    }
     pbase[mi] = (((n - n0) * p.Hp + oy * STRIDE - rr0) * p.Wl + ox * STRIDE) * 8;
   }
   int koff[KSTEPS];
@@ -150,8 +165,12 @@ __global__ __launch_bounds__(256, 2) void conv_small_cin_kernel(const SmallCinPa
   }
 
   __syncthreads();  // LDS tiles are dead: reuse them for the store transpose
-  conv_epilogue<TT, MI, NI>(acc, smem + wave * (16 * (NI * 64 + 16)), m0 + wave * 64, p.M, COUT, 0, p.shift,
-                            (const typename TT::elem*)nullptr, (typename TT::elem*)p.out, p.relu, lane);
+  if (POOL)
+    conv_epilogue_pool2<TT, MI, NI>(acc, smem + wave * (16 * (NI * 64 + 16)), (m0 + wave * 64) >> 2, p.M >> 2, COUT, 0, p.shift,
+                                    (typename TT::elem*)p.out, p.relu, lane);
+  else
+    conv_epilogue<TT, MI, NI>(acc, smem + wave * (16 * (NI * 64 + 16)), m0 + wave * 64, p.M, COUT, 0, p.shift,
+                              (const typename TT::elem*)nullptr, (typename TT::elem*)p.out, p.relu, lane);
 }
 
 static int small_rows_bound(int BM, int Ho, int Wo, int Hp, int stride, int KH) {
@@ -167,16 +186,23 @@ extern "C" int frmap_small_cin_kpad(int KH, int KW) {
   return (KH * kr + 31) / 32 * 32 + 8;
 }
 
-template <typename TT, int NI, int KH, int KW, int STRIDE>
+static int small_pool_rows_bound(int BM, int Ho, int Wo, int Hp, int KH) {
+  const int nw = BM / 4, Wo2 = Wo / 2, Win = (Ho / 2) * Wo2;
+  const int pairs = (nw + Wo2 - 2) / Wo2 + 1, cross = (nw + Win - 2) / Win;
+  const int x = cross < pairs - 1 ? cross : pairs - 1;
+  return 2 * pairs + (Hp - Ho) * x + KH - 1;
+}
+
+template <typename TT, int NI, int KH, int KW, int STRIDE, bool POOL = false>
 static int launch_small(SmallCinParams& p, hipStream_t st) {
   constexpr int KR = (KW * 4 > 16) ? 32 : 16;
   constexpr int KPAD = (KH * KR + 31) / 32 * 32;
   const int wbytes = NI * 16 * (KPAD + 8) * 2;
-  long long hb = (long long)small_rows_bound(256, p.Ho, p.Wo, p.Hp, STRIDE, KH) * p.Wl * 8;
+  long long hb = (long long)(POOL ? small_pool_rows_bound(256, p.Ho, p.Wo, p.Hp, KH) : small_rows_bound(256, p.Ho, p.Wo, p.Hp, STRIDE, KH)) * p.Wl * 8;
   hb = (hb + 1023) & ~1023ll;
   FRMAP_REQUIRE(hb + wbytes <= 160 * 1024, "conv_small_cin: rows too wide for LDS (W=%d)", p.Wi);
   p.halo_bytes = (int)hb;
-  auto kern = conv_small_cin_kernel<TT, NI, KH, KW, STRIDE>;
+  auto kern = conv_small_cin_kernel<TT, NI, KH, KW, STRIDE, POOL>;
   if (frmap_big_lds((const void*)kern, 160 * 1024)) return -2;
   int lds = (int)hb + wbytes;
   const int scratch = 4 * 16 * (NI * 64 + 16);  // epilogue transpose region (4 waves)
@@ -186,9 +212,9 @@ static int launch_small(SmallCinParams& p, hipStream_t st) {
   return 0;
 }
 
-extern "C" int frmap_conv_small_cin(const void* in_nhwc4, const void* w_packed, const float* shift, void* out,
-                                    int B, int Hi, int Wi, int Cout, int KH, int KW, int stride, int pad,
-                                    int relu, int dtype, void* stream) {
+static int small_cin_impl(const void* in_nhwc4, const void* w_packed, const float* shift, void* out,
+                          int B, int Hi, int Wi, int Cout, int KH, int KW, int stride, int pad,
+                          int relu, int dtype, bool pool, void* stream) {
   FRMAP_REQUIRE(in_nhwc4 && w_packed && shift && out, "conv_small_cin: null pointer");
   FRMAP_REQUIRE(dtype == FRMAP_BF16 || dtype == FRMAP_F16, "conv_small_cin: bad dtype %d", dtype);
   const bool stem7 = (KH == 7 && KW == 7 && stride == 2 && pad == 3 && Cout == 64);
@@ -211,6 +237,26 @@ extern "C" int frmap_conv_small_cin(const void* in_nhwc4, const void* w_packed, 
   p.magic_Wl2 = frmap_magic((uint32_t)(p.Wl >> 1)); p.magic_Hp = frmap_magic((uint32_t)p.Hp);
   p.nblocks = (p.M + 255) / 256;
   hipStream_t st = (hipStream_t)stream;
+  memset(&p.pool, 0, sizeof(p.pool));
+  if (pool) {
+    FRMAP_REQUIRE(first3 && p.Ho % 2 == 0 && p.Wo % 2 == 0 && (relu == 0 || relu == 1),
+                  "conv_small_cin_pool2: needs the 3x3 s1 p1 3->32 layer with even H and W (H=%d W=%d)", Hi, Wi);
+    p.pool.Wo2 = p.Wo / 2; p.pool.Win = (p.Ho / 2) * (p.Wo / 2);
+    p.pool.dWo2 = frmap_div_make((uint32_t)p.pool.Wo2); p.pool.dWin = frmap_div_make((uint32_t)p.pool.Win);
+    return dtype == FRMAP_BF16 ? launch_small<BF16, 2, 3, 3, 1, true>(p, st) : launch_small<F16, 2, 3, 3, 1, true>(p, st);
+  }
   if (stem7) return dtype == FRMAP_BF16 ? launch_small<BF16, 4, 7, 7, 2>(p, st) : launch_small<F16, 4, 7, 7, 2>(p, st);
   return dtype == FRMAP_BF16 ? launch_small<BF16, 2, 3, 3, 1>(p, st) : launch_small<F16, 2, 3, 3, 1>(p, st);
+}
+
+extern "C" int frmap_conv_small_cin(const void* in_nhwc4, const void* w_packed, const float* shift, void* out,
+                                    int B, int Hi, int Wi, int Cout, int KH, int KW, int stride, int pad,
+                                    int relu, int dtype, void* stream) {
+  return small_cin_impl(in_nhwc4, w_packed, shift, out, B, Hi, Wi, Cout, KH, KW, stride, pad, relu, dtype, false, stream);
+}
+
+// BaselineNet conv1 + bn1 + ReLU + MaxPool2d(2, 2) (face_models.py:38) in one launch: out = [B][Hi/2][Wi/2][32]
+extern "C" int frmap_conv_small_cin_pool2(const void* in_nhwc4, const void* w_packed, const float* shift, void* out,
+                                          int B, int Hi, int Wi, int Cout, int relu, int dtype, void* stream) {
+  return small_cin_impl(in_nhwc4, w_packed, shift, out, B, Hi, Wi, Cout, 3, 3, 1, 1, relu, dtype, true, stream);
 }

@@ -146,6 +146,54 @@ __device__ __forceinline__ void conv_epilogue(const f32x4_t (&acc)[MI][NI], char
   }
 }
 
+// 2x2 / stride-2 max-pool fused into the epilogue (`self.pool(F.relu(self.bn(self.conv(x))))`, face_models.py:38-40,
+// and SiameseNet's conv -> BN -> ReLU -> MaxPool2d(2) runs, :121-141).  The kernel enumerates its output pixels in
+// POOL-MAJOR order - index m = 4 * window + (dy * 2 + dx) - so the 16 pixels of an MFMA column group are 4 whole
+// pooling windows and a window's 4 pixels sit in 4 consecutive scratch rows: the pooled value is the max over those
+// rows (max and the monotonic shift + ReLU commute: shift + act are applied once, after the max).  Writes pooled
+// pixel (mp_wave0 + mi * 4 + window) as whole 16-byte runs like conv_epilogue.
+template <typename TT, int MI, int NI>
+__device__ __forceinline__ void conv_epilogue_pool2(const f32x4_t (&acc)[MI][NI], char* scratch, int mp_wave0, int MP,
+                                                    int Cout, int co0, const float* __restrict__ shift,
+                                                    typename TT::elem* __restrict__ out, int relu, int lane) {
+  constexpr int PITCH = NI * 64 + 16, PARTS = NI * 2;
+  const int lr = lane & 15, g = lane >> 4;
+  // every lane reads (lanes >= 4 * PARTS redo windows 0..3 and store nothing): a lane that only ever wrote the scratch
+  // would let the compiler drop all but its last write (its own view has no read in between) - seen in the ISA
+  const bool active = lane < 4 * PARTS;
+  const int win = (lane / PARTS) & 3, part = lane % PARTS;
+  float sh[8];
+  {
+    const f32x4_t s0 = *(const f32x4_t*)(shift + co0 + part * 8), s1 = *(const f32x4_t*)(shift + co0 + part * 8 + 4);
+    sh[0] = s0[0]; sh[1] = s0[1]; sh[2] = s0[2]; sh[3] = s0[3];
+    sh[4] = s1[0]; sh[5] = s1[1]; sh[6] = s1[2]; sh[7] = s1[3];
+  }
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) *(f32x4_t*)(scratch + lr * PITCH + ni * 64 + g * 16) = acc[mi][ni];
+    __builtin_amdgcn_wave_barrier();
+    const char* src = scratch + (win * 4) * PITCH + part * 32;
+    f32x4_t a = *(const f32x4_t*)src, b = *(const f32x4_t*)(src + 16);
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+      const f32x4_t a2 = *(const f32x4_t*)(src + q * PITCH), b2 = *(const f32x4_t*)(src + q * PITCH + 16);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a[e] = fmaxf(a[e], a2[e]); b[e] = fmaxf(b[e], b2[e]); }
+    }
+    const int mp = mp_wave0 + mi * 4 + win;
+    if (active && mp < MP) {
+      float v[8] = {a[0] + sh[0], a[1] + sh[1], a[2] + sh[2], a[3] + sh[3], b[0] + sh[4], b[1] + sh[5], b[2] + sh[6], b[3] + sh[7]};
+      if (relu == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      *(u32x4_t*)(out + (size_t)mp * Cout + co0 + part * 8) = pack8<TT>(v);
+    }
+  }
+}
+
 // split-K variant of the epilogue: the raw fp32 accumulator tile goes to this K-slice's slab
 // ([M][Cout] fp32), transposed through LDS the same way so every store is 16 bytes per lane.
 template <int MI, int NI>
@@ -195,6 +243,21 @@ __host__ inline FrmapDiv frmap_div_make(uint32_t d) {
   return r;
 }
 __device__ __forceinline__ int frmap_div(int n, FrmapDiv d) { return d.m ? (int)(__umulhi((uint32_t)n, d.m) >> d.sh) : n; }
+
+// pool-major pixel order (conv_epilogue_pool2): m = 4 * w + q, window w = (n * Ho/2 + py) * Wo/2 + px row-major over the
+// POOLED map, q = dy * 2 + dx inside the 2x2 window  ->  output pixel (n, 2 py + dy, 2 px + dx)
+struct FrmapPoolOrder {
+  FrmapDiv dWin, dWo2;  // divisions by (Ho/2 * Wo/2) and Wo/2
+  int Win, Wo2;
+};
+__device__ __forceinline__ void frmap_pool_coords(int m, const FrmapPoolOrder& o, int& n, int& oy, int& ox) {
+  const int w = m >> 2, q = m & 3;
+  n = frmap_div(w, o.dWin);
+  const int rem = w - n * o.Win;
+  const int py = frmap_div(rem, o.dWo2);
+  oy = 2 * py + (q >> 1);
+  ox = 2 * (rem - py * o.Wo2) + (q & 1);
+}
 
 // host-side error plumbing
 void frmap_set_error(const char* fmt, ...);

@@ -18,6 +18,7 @@ no eager / CPU fallback.  Training (`face_models.py:527-572`, losses `:725-782`)
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -51,6 +52,9 @@ def _bn_scale_shift(bn: nn.Module, bias: Optional[torch.Tensor] = None) -> Tuple
     return scale.contiguous(), shift.contiguous()
 
 
+_POOL_FUSE = os.environ.get("FRMAP_POOL_FUSE", "1") != "0"   # A/B switch: 0 = conv and 2x2 max-pool as two launches
+
+
 class _PackedConv:
     __slots__ = ("wpk", "shift", "cout", "k", "stride", "pad", "small")
 
@@ -71,6 +75,17 @@ class _PackedConv:
         if self.small:
             return ops.conv_small_cin(x, self.wpk, self.shift, self.cout, self.k, self.stride, self.pad, relu)
         return ops.conv_igemm(x, self.wpk, self.shift, self.cout, self.k, self.stride, self.pad, relu, residual)
+
+    def pooled(self, x: torch.Tensor, relu: bool = True) -> torch.Tensor:
+        """conv + shift (+ReLU) + MaxPool2d(2, 2) (`face_models.py:38-40,121-141`): one launch when the kernels take the
+        shape (the conv map never reaches HBM), conv + pool kernels otherwise."""
+        B, H, W, C = x.shape
+        fusable = self.k == 3 and self.stride == 1 and self.pad == 1 and H % 2 == 0 and W % 2 == 0 and _POOL_FUSE
+        if fusable and self.small and self.cout == 32:
+            return ops.conv_small_cin_pool2(x, self.wpk, self.shift, self.cout, relu)
+        if fusable and not self.small and ops.conv_pool2_supported(B, H, W, C, self.cout):
+            return ops.conv_igemm_pool2(x, self.wpk, self.shift, self.cout, relu)
+        return ops.maxpool(self(x, relu), 2, 2, 0)
 
 
 class _PackedLinearAsConv:
@@ -283,9 +298,9 @@ class BaselineNet(_HipModule):
         x = self._check_input(x)
         p = self._get_plan()
         x = self._as_nhwc4(x)
-        x = ops.maxpool(p["c1"](x, relu=True), 2, 2, 0)
-        x = ops.maxpool(p["c2"](x, relu=True), 2, 2, 0)
-        x = ops.maxpool(p["c3"](x, relu=True), 2, 2, 0)
+        x = p["c1"].pooled(x)      # self.pool(F.relu(self.bn1(self.conv1(x)))), `face_models.py:38`
+        x = p["c2"].pooled(x)
+        x = p["c3"].pooled(x)
         f = ops.avgpool_global(x)
         return ops.linear_f32(f, self.fc1.weight.detach(), None, self.fc1.bias.detach(), relu=True)
 

@@ -109,6 +109,22 @@ def conv_small_cin(x4: torch.Tensor, wpk: torch.Tensor, shift: torch.Tensor, Cou
     return out
 
 
+def conv_small_cin_pool2(x4: torch.Tensor, wpk: torch.Tensor, shift: torch.Tensor, Cout: int, relu: bool) -> torch.Tensor:
+    """3x3 s1 p1 conv (Cin = 3 as NHWC4) + shift (+ReLU) + MaxPool2d(2, 2) in one launch (`face_models.py:38`)."""
+    x4 = _dev(x4, "conv_small_cin_pool2.x")
+    B, H, W, C = x4.shape
+    if C != 4:
+        raise ValueError("conv_small_cin_pool2: input must be NHWC4")
+    if H % 2 or W % 2:
+        raise ValueError("conv_small_cin_pool2: H and W must be even")
+    out = torch.empty((B, H // 2, W // 2, Cout), dtype=x4.dtype, device=x4.device)
+    _lib.check(_lib.load().frmap_conv_small_cin_pool2(x4.data_ptr(), _dev(wpk, "wpk").data_ptr(),
+                                                      _dev(shift, "shift", torch.float32).data_ptr(), out.data_ptr(),
+                                                      B, H, W, Cout, int(relu), dt_code(x4.dtype), _stream()),
+               "conv_small_cin_pool2")
+    return out
+
+
 def stem_pool_dims(H: int, W: int):
     Hc, Wc = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
     return (Hc + 2 - 3) // 2 + 1, (Wc + 2 - 3) // 2 + 1
@@ -177,6 +193,27 @@ def conv_igemm(x: torch.Tensor, wpk: torch.Tensor, shift: torch.Tensor, Cout: in
                                             _dev(shift, "shift", torch.float32).data_ptr(), res_ptr, out.data_ptr(),
                                             B, H, W, Cin, Cout, k, stride, pad, int(relu), dt_code(x.dtype),
                                             _stream()), "conv_igemm")
+    return out
+
+
+def conv_pool2_supported(B: int, H: int, W: int, Cin: int, Cout: int) -> bool:
+    return bool(_lib.load().frmap_conv_igemm_pool2_supported(B, H, W, Cin, Cout))
+
+
+def conv_igemm_pool2(x: torch.Tensor, wpk: torch.Tensor, shift: torch.Tensor, Cout: int, relu) -> torch.Tensor:
+    """conv 3x3 s1 p1 + shift (+ReLU) + MaxPool2d(2, 2) in one launch (`face_models.py:39-40,121-141`); the conv map
+    never reaches HBM.  Raises ``ValueError`` for shapes `conv_pool2_supported` rejects."""
+    x = _dev(x, "conv_igemm_pool2.x")
+    B, H, W, Cin = x.shape
+    if wpk.numel() != Cout * Cin * 9 or wpk.dtype != x.dtype:
+        raise ValueError("conv_igemm_pool2: packed weight does not match Cout*Cin*9 / dtype")
+    if shift.numel() != Cout:
+        raise ValueError("conv_igemm_pool2: shift must have Cout elements")
+    out = torch.empty((B, H // 2, W // 2, Cout), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().frmap_conv_igemm_pool2(x.data_ptr(), _dev(wpk, "wpk").data_ptr(),
+                                                  _dev(shift, "shift", torch.float32).data_ptr(), out.data_ptr(),
+                                                  B, H, W, Cin, Cout, int(relu), dt_code(x.dtype), _stream()),
+               "conv_igemm_pool2")
     return out
 
 

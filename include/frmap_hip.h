@@ -79,6 +79,13 @@ int frmap_pack_conv_weight_c3(const float* w_oihw, void* w_packed, int Cout, int
 int frmap_conv_small_cin(const void* in_nhwc4, const void* w_packed, const float* shift, void* out,
                          int B, int Hi, int Wi, int Cout, int KH, int KW, int stride, int pad,
                          int relu, int dtype, void* stream);
+/* The 3x3 s1 p1 3->32 layer with MaxPool2d(2, 2) fused into its epilogue: BaselineNet
+ * `self.pool(F.relu(self.bn1(self.conv1(x))))` (src/face_models.py:38) in one launch.  The kernel walks
+ * its output pixels in pool-major order (4 consecutive pixels = one 2x2 window), so the pooled value is
+ * a max over 4 accumulator rows; the 32×H×W conv map never reaches HBM.  Even Hi, Wi.
+ * out: B×(Hi/2)×(Wi/2)×32. */
+int frmap_conv_small_cin_pool2(const void* in_nhwc4, const void* w_packed, const float* shift, void* out,
+                               int B, int Hi, int Wi, int Cout, int relu, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused ResNet stem: fp32 NCHW B×3×Hi×Wi -> conv 7x7 s2 p3 (3->64) + shift + ReLU -> maxpool 3x3 s2 p1
@@ -122,6 +129,15 @@ int frmap_stem7x7_maxpool_u8(const unsigned char* x_u8_hwc, const float* mean3_h
 int frmap_conv_igemm(const void* in, const void* w_packed, const float* shift, const void* residual,
                      void* out, int B, int Hi, int Wi, int Cin, int Cout, int K, int stride, int pad,
                      int relu, int dtype, void* stream);
+/* conv 3x3 s1 p1 + shift (+ReLU) + MaxPool2d(2, 2) in one launch: BaselineNet conv2/conv3 blocks
+ * (src/face_models.py:39-40) and SiameseNet's conv -> BN -> ReLU -> MaxPool2d(2) runs (:121-141).
+ * relu in {0, 1} (the max is taken before shift + activation, which is exact for monotonic ones).
+ * out: B×(Hi/2)×(Wi/2)×Cout.  frmap_conv_igemm_pool2_supported: 1 when the shape is taken (even Hi and Wi,
+ * Cin % 32 == 0, Cout % 64 == 0, the tile's input rows fit LDS); otherwise run frmap_conv_igemm +
+ * frmap_maxpool. */
+int frmap_conv_igemm_pool2_supported(int B, int Hi, int Wi, int Cin, int Cout);
+int frmap_conv_igemm_pool2(const void* in, const void* w_packed, const float* shift, void* out, int B, int Hi,
+                           int Wi, int Cin, int Cout, int relu, int dtype, void* stream);
 
 /* Tuning / test hook for the second-generation 3x3 stride-1 kernel behind frmap_conv_igemm (conv_pp.hip: 8-wave
  * workgroups, LDS-DMA operands): enable (0 / 1, -1 = default), pixels per tile (<= 224, -1 = whole rows / images),

@@ -530,3 +530,47 @@ def test_conv_pp_fused_shortcut():
                 assert torch.allclose(y_pp.float(), y_g1.float(), atol=atol, rtol=rtol), (ci, dtype, "generations differ")
     finally:
         lib.frmap_conv_pp_tuning(-1, -1, -1)
+
+
+def test_conv_fused_maxpool2x2():
+    """conv 3x3 s1 p1 + shift + ReLU + MaxPool2d(2, 2) in one launch (`face_models.py:38-40,121-141`; pool-major pixel
+    order + conv_epilogue_pool2) against fp32 torch and against the two-launch path: the BaselineNet / SiameseNet shapes,
+    windows that straddle tile and image boundaries, ragged batches, no activation, the Cin = 3 first layer."""
+    cases = [  # B, H, W, Cin, Cout, relu
+        (2, 112, 112, 32, 64, 1), (3, 56, 56, 64, 128, 1), (5, 6, 6, 64, 64, 1), (3, 12, 20, 32, 64, 0), (7, 2, 2, 32, 64, 1),
+        (2, 56, 56, 128, 128, 1), (3, 28, 28, 256, 256, 1), (1, 4, 130, 32, 128, 1), (9, 14, 10, 96, 192, 1),
+    ]
+    for ci, (B, H, W, Cin, Cout, relu) in enumerate(cases):
+        for dtype in DTYPES:
+            h = synth.randn(9700 + ci, (B, Cin, H, W), "h").to(dtype)
+            w = (synth.randn(9710 + ci, (Cout, Cin, 3, 3), "w") * math.sqrt(2.0 / (Cin * 9))).to(dtype)
+            shift = synth.randn(9720 + ci, (Cout,), "b") * 0.1
+            ref = F.conv2d(h.float(), w.float(), None, padding=1) + shift.view(1, -1, 1, 1)
+            ref = F.max_pool2d(F.relu(ref) if relu else ref, 2, 2)
+            assert ops.conv_pool2_supported(B, H, W, Cin, Cout), (ci, "not taken")
+            x, wpk, sh = _nhwc(h).to(DEV), ops.pack_conv_weight(w.float().to(DEV), dtype), shift.to(DEV)
+            y = ops.conv_igemm_pool2(x, wpk, sh, Cout, relu)
+            y2 = ops.maxpool(ops.conv_igemm(x, wpk, sh, Cout, 3, 1, 1, relu), 2, 2, 0)
+            atol, rtol = _tol(dtype)
+            yc = y.float().cpu().permute(0, 3, 1, 2)
+            assert yc.shape == ref.shape
+            assert torch.allclose(yc, ref, atol=atol, rtol=rtol), (ci, dtype, float((yc - ref).abs().max()))
+            assert torch.allclose(y.float(), y2.float(), atol=atol, rtol=rtol), (ci, dtype, "fused and two-launch paths differ")
+    for ci, (B, H, W) in enumerate([(2, 224, 224), (3, 10, 14), (1, 2, 2), (5, 36, 18)]):   # BaselineNet conv1 (Cin = 3 as NHWC4)
+        for dtype in DTYPES:
+            h = synth.randn(9750 + ci, (B, 3, H, W), "h").to(dtype)
+            w = (synth.randn(9760 + ci, (32, 3, 3, 3), "w") * math.sqrt(2.0 / 27)).to(dtype)
+            shift = synth.randn(9770 + ci, (32,), "b") * 0.1
+            ref = F.max_pool2d(F.relu(F.conv2d(h.float(), w.float(), None, padding=1) + shift.view(1, -1, 1, 1)), 2, 2)
+            x4 = torch.zeros(B, H, W, 4, dtype=dtype)
+            x4[..., :3] = h.permute(0, 2, 3, 1)
+            x4, wpk, sh = x4.to(DEV), ops.pack_conv_weight_c3(w.float().to(DEV), dtype), shift.to(DEV)
+            y = ops.conv_small_cin_pool2(x4, wpk, sh, 32, True)
+            y2 = ops.maxpool(ops.conv_small_cin(x4, wpk, sh, 32, 3, 1, 1, True), 2, 2, 0)
+            atol, rtol = _tol(dtype)
+            yc = y.float().cpu().permute(0, 3, 1, 2)
+            assert torch.allclose(yc, ref, atol=atol, rtol=rtol), ("c3", ci, dtype, float((yc - ref).abs().max()))
+            assert torch.equal(y, y2), ("c3", ci, dtype, "fused and two-launch paths differ")
+    with pytest.raises(ValueError):
+        ops.conv_igemm_pool2(torch.zeros(1, 5, 6, 32, dtype=torch.bfloat16, device=DEV),
+                             torch.zeros(64 * 32 * 9, dtype=torch.bfloat16, device=DEV), torch.zeros(64, device=DEV), 64, True)
