@@ -497,9 +497,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fast_kernel(const ConvParams p
 // tile's 8 residual pieces, and the PREVIOUS tile's 8 packed output pieces (each one an 8-pixel x
 // 64-channel row segment = 1 KB contiguous), which the epilogue leaves in registers.
 // ================================================================================================
-template <typename TT>
+// NCH = channel chunks (2: Cin = 64; 1: Cin = 32, no residual).  POOL = true: MaxPool2d(2, 2) fused (BaselineNet conv2 /
+// conv3, face_models.py:39-40): the patch's pixels are walked in pool-major order (fragment row i of pixel group mi =
+// window i >> 2 of pooled row mi, pixel i & 3 of it), the transpose takes the max over each window's 4 scratch rows and
+// the tile leaves 2 packed pieces (its 4x4 pooled patch) instead of 8.
+template <typename TT, int NCH = 2, bool POOL = false>
 __global__ __launch_bounds__(512, 1) void conv3x3_c64_wave_kernel(const ConvParams p) {
-  constexpr int MI = 4, NI = 4, TAPS = 9, NH = 7, NO = 8, NG = TAPS * NI, NL = NO + NH;
+  constexpr int MI = 4, NI = 4, TAPS = 9, NH = 7, NO = POOL ? 2 : 8, NG = TAPS * NI, NL = NO + NH;
   constexpr int PITCH = NI * 64 + 16, HALO = 10 * 16 * 64;
   using vec8 = typename TT::vec8;
   using elem = typename TT::elem;
@@ -507,7 +511,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_wave_kernel(const ConvPara
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, g = lane >> 4;
-  constexpr int wbytes = 2 * TAPS * 4096;  // both chunks
+  constexpr int wbytes = NCH * TAPS * 4096;  // every chunk
   char* wl = smem;
   char* halo = smem + wbytes + wave * HALO;
 
@@ -538,9 +542,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_wave_kernel(const ConvPara
   const int woff = (lr << 6) + ((g ^ (((lr >> 2) & 1) << 1)) << 4);
   const elem* inp = (const elem*)p.in;
   const int img_bytes = p.Hi * p.Wi * p.Cin * (int)sizeof(elem);
-  const int row_in = p.Wi * p.Cin * (int)sizeof(elem), row_out = p.Wo * p.Cout * (int)sizeof(elem);
+  // POOL: the output map is the pooled one (Wo / 2 wide, 4x4 pooled pixels per patch)
+  const int row_in = p.Wi * p.Cin * (int)sizeof(elem), row_out = (POOL ? p.Wo >> 1 : p.Wo) * p.Cout * (int)sizeof(elem);
   // output / residual piece u (= output row u of the patch): lane -> pixel column lane >> 3, channels (lane & 7) * 8 ..+7
-  const int io_lane = ((lane >> 3) * p.Cout + co0 + (lane & 7) * 8) * (int)sizeof(elem);
+  // POOL: piece u = pooled rows 2u, 2u + 1: lane -> pooled row 2u + (lane >> 5), pooled column (lane >> 3) & 3
+  const int io_lane = POOL ? (int)(lane >> 5) * row_out + ((((lane >> 3) & 3) * p.Cout + co0 + (lane & 7) * 8) * (int)sizeof(elem))
+                           : ((lane >> 3) * p.Cout + co0 + (lane & 7) * 8) * (int)sizeof(elem);
+  const int io_step = POOL ? 2 * row_out : row_out;   // byte step between pieces
   float sh[8];
   {
     const f32x4_t s0 = *(const f32x4_t*)(p.shift + co0 + (lane & 7) * 8), s1 = *(const f32x4_t*)(p.shift + co0 + (lane & 7) * 8 + 4);
@@ -549,7 +557,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_wave_kernel(const ConvPara
   // fragment row i of pixel group mi = output pixel (mi*2 + (i >> 3), i & 7) of the patch = halo pixel (+kh, +kw)
   int A[MI];
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) A[mi] = ((((mi * 2 + (lr >> 3)) << 4) + (lr & 7)) << 6) | (g << 4);
+  for (int mi = 0; mi < MI; ++mi)
+    A[mi] = POOL ? ((((mi * 2 + ((lr >> 1) & 1)) << 4) + ((lr >> 2) * 2 + (lr & 1))) << 6) | (g << 4)
+                 : ((((mi * 2 + (lr >> 3)) << 4) + (lr & 7)) << 6) | (g << 4);
 
   // halo piece u of this lane: q = u*64 + lane -> halo pixel q >> 2 = (pr, pc) of the 10x10 patch, channel group q & 3
   unsigned soff[NH];
@@ -571,8 +581,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_wave_kernel(const ConvPara
     }
   };
   auto io_rsrc = [&](const void* base, int n, int by, int bx, bool live) {  // descriptor at the patch's first pixel
-    const size_t el = (((size_t)n * p.Ho + by * 8) * p.Wo + bx * 8) * p.Cout;
-    return __builtin_amdgcn_make_buffer_rsrc((void*)((const elem*)base + el), (short)0, live ? 8 * row_out : 0, 0x00020000);
+    const size_t el = POOL ? (((size_t)n * (p.Ho >> 1) + by * 4) * (p.Wo >> 1) + bx * 4) * p.Cout
+                           : (((size_t)n * p.Ho + by * 8) * p.Wo + bx * 8) * p.Cout;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const elem*)base + el), (short)0, live ? (POOL ? 4 : 8) * row_out : 0, 0x00020000);
   };
 
   setup_load(T, true);
@@ -589,7 +600,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_wave_kernel(const ConvPara
       for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
-    for (int chunk = 0; chunk < 2; ++chunk) {
+    for (int chunk = 0; chunk < NCH; ++chunk) {
       // stage: this wave's halo pieces -> its private image (LDS is in order: earlier fragment reads are served first)
 #pragma unroll
       for (int u = 0; u < NH; ++u) {
@@ -600,12 +611,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_wave_kernel(const ConvPara
       // ---- what rides between this phase's MFMAs
       //  chunk 0: the previous tile's 8 output pieces (stores), then chunk 1's 7 halo pieces
       //  chunk 1: this tile's 8 residual pieces (into ov[]), then the next tile's chunk-0 halo pieces
+      //  (NCH = 1: one chunk does both - the previous tile's stores and the next tile's halo pieces; POOL: no residual)
       __amdgpu_buffer_rsrc_t rs_io;
       int pso = 64;
-      if (chunk == 0) {
-        rs_io = io_rsrc(p.out, p_n < 0 ? 0 : p_n, p_by, p_bx, p_n >= 0);
-      } else {
-        rs_io = io_rsrc(p.res ? p.res : p.out, c_n, c_by, c_bx, p.res != nullptr);
+      if (chunk == 0) rs_io = io_rsrc(p.out, p_n < 0 ? 0 : p_n, p_by, p_bx, p_n >= 0);
+      else rs_io = io_rsrc(p.res ? p.res : p.out, c_n, c_by, c_bx, p.res != nullptr && !POOL);
+      if (chunk == NCH - 1) {
         pso = 0;
         const int Tn = tile_of(rnd + 1);
         const bool more = Tn >= 0;
@@ -613,8 +624,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_wave_kernel(const ConvPara
       }
       auto memop = [&](int i) {
         if (i < NO) {
-          if (chunk == 0) __builtin_amdgcn_raw_buffer_store_b128(ov[i], rs_io, io_lane, i * row_out, 0);
-          else ov[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_io, io_lane, i * row_out, 0);
+          if (chunk == 0) __builtin_amdgcn_raw_buffer_store_b128(ov[i], rs_io, io_lane, i * io_step, 0);
+          else if (!POOL) ov[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_io, io_lane, i * io_step, 0);
         } else {
           hv[i - NO] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)soff[i - NO], pso, 0);
         }
@@ -650,6 +661,33 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_wave_kernel(const ConvPara
         }
       }
     }
+    if constexpr (POOL) {
+      // ---- pooled epilogue: two pixel groups (= pooled rows mp, mp + 1) per pass; every lane takes one pooled pixel's
+      //      8-channel run: the max over the window's 4 scratch rows, + shift, activation, round once
+#pragma unroll
+      for (int mp = 0; mp < MI; mp += 2) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) *(f32x4_t*)(halo + h * (16 * PITCH) + lr * PITCH + ni * 64 + g * 16) = acc[mp + h][ni];
+        __builtin_amdgcn_wave_barrier();
+        const char* src = halo + (lane >> 5) * (16 * PITCH) + (((lane >> 3) & 3) * 4) * PITCH + (lane & 7) * 32;
+        f32x4_t a = *(const f32x4_t*)src, b = *(const f32x4_t*)(src + 16);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+          const f32x4_t a2 = *(const f32x4_t*)(src + q * PITCH), b2 = *(const f32x4_t*)(src + q * PITCH + 16);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { a[e] = fmaxf(a[e], a2[e]); b[e] = fmaxf(b[e], b2[e]); }
+        }
+        float v[8] = {a[0] + sh[0], a[1] + sh[1], a[2] + sh[2], a[3] + sh[3], b[0] + sh[4], b[1] + sh[5], b[2] + sh[6], b[3] + sh[7]};
+        if (p.relu == 1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        ov[mp >> 1] = pack8<TT>(v);
+      }
+    } else {
     // ---- epilogue without stores: transpose two pixel groups at a time through the (now free) halo image,
     //      + shift (+ residual from ov[]) (activation), round once, leave the 8 packed pieces in ov[]
 #pragma unroll
@@ -682,13 +720,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_wave_kernel(const ConvPara
           ov[u] = pack8<TT>(v);
         }
     }
+    }
     p_n = c_n; p_by = c_by; p_bx = c_bx;
   }
   // the last tile's outputs
   if (p_n >= 0) {
     const __amdgpu_buffer_rsrc_t rs_o = io_rsrc(p.out, p_n, p_by, p_bx, true);
 #pragma unroll
-    for (int i = 0; i < NO; ++i) __builtin_amdgcn_raw_buffer_store_b128(ov[i], rs_o, io_lane, i * row_out, 0);
+    for (int i = 0; i < NO; ++i) __builtin_amdgcn_raw_buffer_store_b128(ov[i], rs_o, io_lane, i * io_step, 0);
   }
 }
 
@@ -1099,6 +1138,30 @@ static int launch(const ConvParams& p, int lds_bytes, hipStream_t st) {
   return 0;
 }
 
+// conv3x3_c64_wave_kernel: one 8-wave workgroup per CU (per channel tile), each wave walks 8x8 patches
+template <int NCH, bool POOL>
+static int launch_wave(const ConvParams& p, int dtype, hipStream_t st) {
+  const int ntiles = p.Cout / 64, total = p.N * (p.Hi / 8) * (p.Wi / 8);
+  int cus = 256;
+  {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  int per = cus / ntiles;
+  if (per < 1) per = 1;
+  if (per > (total + 7) / 8) per = (total + 7) / 8;
+  const int grid = per * ntiles;
+  const int ldsw = NCH * 9 * 4096 + 8 * (10 * 16 * 64);
+  const void* kern = dtype == FRMAP_BF16 ? (const void*)conv3x3_c64_wave_kernel<BF16, NCH, POOL> : (const void*)conv3x3_c64_wave_kernel<F16, NCH, POOL>;
+  if (frmap_big_lds(kern, 160 * 1024)) return -2;
+  if (dtype == FRMAP_BF16)
+    hipLaunchKernelGGL((conv3x3_c64_wave_kernel<BF16, NCH, POOL>), dim3(grid), dim3(512), ldsw, st, p);
+  else
+    hipLaunchKernelGGL((conv3x3_c64_wave_kernel<F16, NCH, POOL>), dim3(grid), dim3(512), ldsw, st, p);
+  FRMAP_LAUNCH_CHECK();
+  return 0;
+}
+
 struct DsArgs {  // fused projection shortcut (conv3x3_fast_kernel<TT, true>); in == nullptr: none
   const void* in;
   const void* w;
@@ -1221,25 +1284,7 @@ static int conv_igemm_impl(const void* in, const void* w_packed, const float* sh
     if (wres < 0) { const char* e = getenv("FRMAP_CONV_WRES"); wres = e ? atoi(e) : 1; }
     if (wres && !ds.in && stride == 1 && p.dbg == 0 && Cin == 64 && Hi % 8 == 0 && Wi % 8 == 0 &&
         (long long)Hi * Wi * Cin * 2 < (1ll << 31) && (long long)8 * Wo * Cout * 2 < (1ll << 31)) {
-      const int total = B * (Hi / 8) * (Wi / 8);
-      int cus = 256;
-      {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-      }
-      int per = cus / ntiles;
-      if (per < 1) per = 1;
-      if (per > (total + 7) / 8) per = (total + 7) / 8;
-      const int grid = per * ntiles;
-      const int ldsw = 2 * wbytes + 8 * (10 * 16 * 64);
-      const void* kern = dtype == FRMAP_BF16 ? (const void*)conv3x3_c64_wave_kernel<BF16> : (const void*)conv3x3_c64_wave_kernel<F16>;
-      if (frmap_big_lds(kern, 160 * 1024)) return -2;
-      if (dtype == FRMAP_BF16)
-        hipLaunchKernelGGL(conv3x3_c64_wave_kernel<BF16>, dim3(grid), dim3(512), ldsw, st, p);
-      else
-        hipLaunchKernelGGL(conv3x3_c64_wave_kernel<F16>, dim3(grid), dim3(512), ldsw, st, p);
-      FRMAP_LAUNCH_CHECK();
-      return 0;
+      return launch_wave<2, false>(p, dtype, st);
     }
   }
   if (ds.in) FRMAP_REQUIRE(fastk, "conv_igemm_ds: layer does not take the register-prefetch kernel");
@@ -1350,6 +1395,14 @@ extern "C" int frmap_conv_igemm_pool2(const void* in, const void* w_packed, cons
   p.nchunks = Cin / 32; p.ksplit = 1; p.slab = nullptr; p.dbg = 0;
   p.pool.Wo2 = Wi / 2; p.pool.Win = (Hi / 2) * (Wi / 2);
   p.pool.dWo2 = frmap_div_make((uint32_t)p.pool.Wo2); p.pool.dWin = frmap_div_make((uint32_t)p.pool.Win);
+  hipStream_t st = (hipStream_t)stream;
+  {  // Cin = 32 / 64 on 8-aligned maps: the weights-resident wave-autonomous kernel, pooled epilogue (BaselineNet conv2, conv3)
+    static int wres = -1;
+    if (wres < 0) { const char* e = getenv("FRMAP_POOL_WAVE"); wres = e ? atoi(e) : 1; }
+    if (wres && (Cin == 32 || Cin == 64) && Hi % 8 == 0 && Wi % 8 == 0 && (long long)Hi * Wi * Cin * 2 < (1ll << 31) &&
+        (long long)4 * (Wi / 2) * Cout * 2 < (1ll << 31))
+      return Cin == 64 ? launch_wave<2, true>(p, dtype, st) : launch_wave<1, true>(p, dtype, st);
+  }
   const int wbytes = 9 * 4096, ntiles = Cout / 64;
   int BM = 256;
   long long hb = (long long)pool_rows_bound(256, Hi, Wi, p.Hp) * p.Wp * 64;
@@ -1361,7 +1414,6 @@ extern "C" int frmap_conv_igemm_pool2(const void* in, const void* w_packed, cons
   p.halo_bytes = (int)hb;
   p.nblocks = ((p.M + BM - 1) / BM) * ntiles;
   const int lds = p.halo_bytes + wbytes;
-  hipStream_t st = (hipStream_t)stream;
   if (BM == 256) return dtype == FRMAP_BF16 ? launch<BF16, 256, 3, 1, true>(p, lds, st) : launch<F16, 256, 3, 1, true>(p, lds, st);
   return dtype == FRMAP_BF16 ? launch<BF16, 128, 3, 1, true>(p, lds, st) : launch<F16, 128, 3, 1, true>(p, lds, st);
 }

@@ -539,6 +539,7 @@ def test_conv_fused_maxpool2x2():
     cases = [  # B, H, W, Cin, Cout, relu
         (2, 112, 112, 32, 64, 1), (3, 56, 56, 64, 128, 1), (5, 6, 6, 64, 64, 1), (3, 12, 20, 32, 64, 0), (7, 2, 2, 32, 64, 1),
         (2, 56, 56, 128, 128, 1), (3, 28, 28, 256, 256, 1), (1, 4, 130, 32, 128, 1), (9, 14, 10, 96, 192, 1),
+        (5, 8, 24, 32, 64, 1), (3, 16, 8, 64, 192, 0), (37, 8, 8, 64, 64, 1),   # 8-aligned maps with Cin 32 / 64: the wave-autonomous kernel
     ]
     for ci, (B, H, W, Cin, Cout, relu) in enumerate(cases):
         for dtype in DTYPES:
