@@ -31,6 +31,8 @@ PROTOTYPES = {
     "frmap_conv_small_cin": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "frmap_conv_small_cin_pool2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "frmap_conv_igemm_pool2_supported": (_i, [_i, _i, _i, _i, _i]),
+    "frmap_conv_igemm_pool2_form": (_i, [_i, _i, _i, _i, _i]),
+    "frmap_conv3x3_pp_pool_layout": (_i, [_i, _i, _i, _i, _i]),
     "frmap_conv_igemm_pool2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "frmap_stem7x7_maxpool": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "frmap_stem7x7_maxpool2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

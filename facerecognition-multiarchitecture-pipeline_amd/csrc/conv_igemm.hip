@@ -1369,19 +1369,36 @@ static int pool_rows_bound(int BM, int Ho, int Wo, int Hp) {
   return 2 * pairs + 2 * x + 2;
 }
 
-extern "C" int frmap_conv_igemm_pool2_supported(int B, int Hi, int Wi, int Cin, int Cout) {
+// which fused form takes the shape: 3 = ping-pong kernel (conv_pp.hip), 2 = wave-autonomous kernel (Cin 32 / 64, 8-aligned
+// maps), 1 = the generic kernel, 0 = none (odd sizes, rows too wide for LDS)
+static int pool2_form(int B, int Hi, int Wi, int Cin, int Cout) {
   if (B <= 0 || Hi <= 0 || Wi <= 0 || Hi % 2 || Wi % 2 || Cin <= 0 || Cin % 32 || Cout <= 0 || Cout % 64) return 0;
   if ((long long)B * Hi * Wi >= (1ll << 31) || Wi + 2 >= 32768 || Hi + 2 >= 32768) return 0;
+  static int wres = -1, minc = 128;
+  if (wres < 0) { const char* e = getenv("FRMAP_POOL_WAVE"); wres = e ? atoi(e) : 1; const char* e2 = getenv("FRMAP_PP_POOL_MIN_CIN"); minc = e2 ? atoi(e2) : 128; }
+  if (Cin >= minc && frmap_conv3x3_pp_pool(nullptr, nullptr, nullptr, nullptr, B, Hi, Wi, Cin, Cout, 0, FRMAP_BF16, nullptr) == 1) return 3;
+  if (wres && (Cin == 32 || Cin == 64) && Hi % 8 == 0 && Wi % 8 == 0 && (long long)Hi * Wi * Cin * 2 < (1ll << 31) &&
+      (long long)4 * (Wi / 2) * Cout * 2 < (1ll << 31))
+    return 2;
   const long long hb = (long long)pool_rows_bound(128, Hi, Wi, Hi + 2) * (Wi + 2) * 64;
-  return hb + 9 * 4096 <= 160 * 1024 && hb / 64 < 65536;
+  return (hb + 9 * 4096 <= 160 * 1024 && hb / 64 < 65536) ? 1 : 0;
 }
+
+// 1 = fusing is expected to win (a fast fused form takes the shape, or the layer is narrow enough that the generic fused
+// kernel beats conv + pool launches); frmap_conv_igemm_pool2 itself runs every shape pool2_form() accepts.
+extern "C" int frmap_conv_igemm_pool2_supported(int B, int Hi, int Wi, int Cin, int Cout) {
+  const int f = pool2_form(B, Hi, Wi, Cin, Cout);
+  return f >= 2 || (f == 1 && Cin <= 96);
+}
+extern "C" int frmap_conv_igemm_pool2_form(int B, int Hi, int Wi, int Cin, int Cout) { return pool2_form(B, Hi, Wi, Cin, Cout); }
 
 extern "C" int frmap_conv_igemm_pool2(const void* in, const void* w_packed, const float* shift, void* out, int B, int Hi,
                                       int Wi, int Cin, int Cout, int relu, int dtype, void* stream) {
   FRMAP_REQUIRE(in && w_packed && shift && out, "conv_igemm_pool2: null pointer");
   FRMAP_REQUIRE(dtype == FRMAP_BF16 || dtype == FRMAP_F16, "conv_igemm_pool2: bad dtype %d", dtype);
   FRMAP_REQUIRE(relu == 0 || relu == 1, "conv_igemm_pool2: activation %d does not commute with the max", relu);
-  FRMAP_REQUIRE(frmap_conv_igemm_pool2_supported(B, Hi, Wi, Cin, Cout),
+  const int form = pool2_form(B, Hi, Wi, Cin, Cout);
+  FRMAP_REQUIRE(form != 0,
                 "conv_igemm_pool2: shape B=%d %dx%d Cin=%d Cout=%d not taken (even H and W, Cin %% 32 == 0, Cout %% 64 == 0, rows fit LDS)",
                 B, Hi, Wi, Cin, Cout);
   ConvParams p;
@@ -1396,13 +1413,13 @@ extern "C" int frmap_conv_igemm_pool2(const void* in, const void* w_packed, cons
   p.pool.Wo2 = Wi / 2; p.pool.Win = (Hi / 2) * (Wi / 2);
   p.pool.dWo2 = frmap_div_make((uint32_t)p.pool.Wo2); p.pool.dWin = frmap_div_make((uint32_t)p.pool.Win);
   hipStream_t st = (hipStream_t)stream;
-  {  // Cin = 32 / 64 on 8-aligned maps: the weights-resident wave-autonomous kernel, pooled epilogue (BaselineNet conv2, conv3)
-    static int wres = -1;
-    if (wres < 0) { const char* e = getenv("FRMAP_POOL_WAVE"); wres = e ? atoi(e) : 1; }
-    if (wres && (Cin == 32 || Cin == 64) && Hi % 8 == 0 && Wi % 8 == 0 && (long long)Hi * Wi * Cin * 2 < (1ll << 31) &&
-        (long long)4 * (Wi / 2) * Cout * 2 < (1ll << 31))
-      return Cin == 64 ? launch_wave<2, true>(p, dtype, st) : launch_wave<1, true>(p, dtype, st);
+  if (form == 3) {
+    const int rc = frmap_conv3x3_pp_pool(in, w_packed, shift, out, B, Hi, Wi, Cin, Cout, relu, dtype, st);
+    if (rc < 0) return rc;
+    if (rc == 1) return 0;
   }
+  // Cin = 32 / 64 on 8-aligned maps: the weights-resident wave-autonomous kernel, pooled epilogue (BaselineNet conv2, conv3)
+  if (form == 2) return Cin == 64 ? launch_wave<2, true>(p, dtype, st) : launch_wave<1, true>(p, dtype, st);
   const int wbytes = 9 * 4096, ntiles = Cout / 64;
   int BM = 256;
   long long hb = (long long)pool_rows_bound(256, Hi, Wi, p.Hp) * p.Wp * 64;

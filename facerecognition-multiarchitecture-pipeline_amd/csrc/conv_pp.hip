@@ -50,6 +50,9 @@ struct PPParams {
   const void* ds_in;   // [N][ds_Hi][ds_Wi][ds_Cin]
   const void* ds_w;    // packed like a 1x1 conv: [Cout/64][ds_Cin/32][1][64][4][8]
   int ds_Hi, ds_Wi, ds_Cin, ds_stride, dsc;   // dsc = ds_Cin / 32
+  // fused MaxPool2d(2, 2) (PL = true): each wave's 112-pixel slice (whole row pairs) is walked in pool-major order
+  int Wo2;         // Wi / 2
+  FrmapDiv dWo2;
 };
 
 __device__ __attribute__((aligned(4096))) unsigned int g_pp_zero[1024];
@@ -103,9 +106,14 @@ __device__ __forceinline__ void pp_static_for(std::integer_sequence<int, Is...>,
 // LOAD segment shrinks to the fragment reads and the waits, so it hides under the other group's MFMA segment; the prefetch
 // distance grows to 3 k-steps (a slab is re-targeted in the MFMA segment after the phase that last read it has retired
 // its reads), and the wait that closes LOAD(k) leaves exactly MFMA(k-1)'s DMA in flight.
-template <typename TT, int MI, int WM, int NHP, int KS, bool DS, bool IM = false>
+// PL = true (pixel-split layouts, tile = WM full slices, 112 % (2 * Wi) == 0): MaxPool2d(2, 2) fused - a slice is whole row
+// pairs, its pixels are enumerated window by window (fragment row i of the slice = pixel i & 3 of window i >> 2), the
+// epilogue takes the max over each window's 4 transpose rows and writes the pooled map (conv_epilogue_pool2); SiameseNet
+// conv.7-10 / conv.14-17 (face_models.py:127-141).
+template <typename TT, int MI, int WM, int NHP, int KS, bool DS, bool IM = false, bool PL = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
   static_assert(!(DS && KS == 2), "the fused shortcut is built for the pixel-split layouts only");
+  static_assert(!PL || (KS == 1 && !DS && !IM), "the pooled epilogue is built for the plain pixel-split layouts");
   static_assert(!(DS && IM), "the fused shortcut keeps its DMA in the LOAD segments");
   constexpr int NI = 4, WN = KS == 2 ? 2 : 8 / WM;
   constexpr int CAP = WM * MI * 16;                          // pixels a tile can hold (KS = 1)
@@ -236,7 +244,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
   int A[MI];  // (pixel index in the halo image) * 64 + k-group * 16, before the tap offset and the swizzle
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
-    const int m = min(m0 + (mslice * MI + mi) * 16 + lr, mend - 1);
+    int m = m0 + (mslice * MI + mi) * 16 + lr;
+    if (PL) {   // pool-major inside the slice: window w = i >> 2 -> (row pair w / Wo2, column pair w % Wo2), pixel i & 3 of it
+      const int i = mi * 16 + lr, w = i >> 2, pr = frmap_div(w, p.dWo2);
+      m = m0 + mslice * (MI * 16) + (2 * pr + ((i >> 1) & 1)) * p.Wi + 2 * (w - pr * p.Wo2) + (i & 1);
+    }
+    m = min(m, mend - 1);
     const int n = frmap_div(m, p.dHoWo), rem = m - n * p.HoWo, oy = frmap_div(rem, p.dWo), ox = rem - oy * p.Wi;
     A[mi] = ((((n - n0) * p.Hp + oy - oy0) * p.Wp + ox) << 6) | (g << 4);
   }
@@ -397,8 +410,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
   }
 
   // ---- epilogue: + shift (+ residual) (activation) -> NHWC, whole-line 16-byte stores via a per-wave LDS transpose
-  conv_epilogue<TT, MI, NI>(acc, smem + (KS == 2 ? q : wave) * (16 * (NI * 64 + 16)), m0 + mslice * (MI * 16), mend, p.Cout,
-                            nt * BN + wn * 64, p.shift, (const elem*)p.res, (elem*)p.out, p.relu, lane);
+  if constexpr (PL)
+    conv_epilogue_pool2<TT, MI, NI>(acc, smem + wave * (16 * (NI * 64 + 16)), (m0 + mslice * (MI * 16)) >> 2, mend >> 2, p.Cout,
+                                    nt * BN + wn * 64, p.shift, (elem*)p.out, p.relu, lane);
+  else
+    conv_epilogue<TT, MI, NI>(acc, smem + (KS == 2 ? q : wave) * (16 * (NI * 64 + 16)), m0 + mslice * (MI * 16), mend, p.Cout,
+                              nt * BN + wn * 64, p.shift, (const elem*)p.res, (elem*)p.out, p.relu, lane);
 }
 
 // ================================================================================================
@@ -748,6 +765,69 @@ int frmap_conv3x3_pp(const void* in, const void* w_packed, const float* shift, c
   rc = dtype == FRMAP_BF16 ? PP_GO(BF16) : PP_GO(F16);
 #undef PP_GO
   return rc ? rc : 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv3x3 s1 p1 + shift (+ReLU) + MaxPool2d(2, 2) on the ping-pong kernel (PL = true).  Takes maps whose row pairs tile a
+// wave's 112-pixel slice (Wi in {2, 4, 8, 14, 28, 56}, even Hi), Cin % 32 == 0, Cout % 128 == 0; tiles are WM whole slices.
+// 1 = launched, 0 = shape not taken, < 0 = error; in == nullptr: plan only.
+// ------------------------------------------------------------------------------------------------
+template <typename TT, int WM, int NHP>
+static int pp_launch_pool(const PPParams& p, hipStream_t st) {
+  auto kern = conv3x3_pp_kernel<TT, 7, WM, NHP, 1, false, false, true>;
+  if (frmap_big_lds((const void*)kern, 160 * 1024)) return -2;
+  const int wb = (8 / WM) * 64 * 64;
+  int lds = 2 * NHP * 8 * 1024 + 4 * wb;
+  const int scratch = 8 * 16 * (4 * 64 + 16);
+  if (lds < scratch) lds = scratch;
+  hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles), dim3(512), lds, st, p);
+  FRMAP_LAUNCH_CHECK();
+  return 0;
+}
+
+int frmap_conv3x3_pp_pool(const void* in, const void* w_packed, const float* shift, void* out, int B, int Hi, int Wi, int Cin,
+                          int Cout, int relu, int dtype, hipStream_t st) {
+  static int on = -1;
+  if (on < 0) on = pp_env("FRMAP_CONV_PP", 1) && pp_env("FRMAP_CONV_PP_POOL", 1);
+  if (g_pp_on >= 0 ? !g_pp_on : !on) return 0;
+  if (Hi % 2 || Wi % 2 || 112 % (2 * Wi) || Cin % 32 || Cin > 1024 || Cout % 128) return 0;
+  const long long Mll = (long long)B * Hi * Wi;
+  if (Mll >= (1ll << 31) || (long long)B * Hi * Wi * Cin * 2 >= (1ll << 46)) return 0;
+  PPParams p;
+  p.in = in; p.wpk = w_packed; p.shift = shift; p.res = nullptr; p.out = out;
+  p.N = B; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
+  p.M = (int)Mll; p.HoWo = Hi * Wi; p.Hp = Hi + 2; p.Wp = Wi + 2;
+  p.magic_Wp = frmap_magic((uint32_t)p.Wp); p.magic_Hp = frmap_magic((uint32_t)p.Hp);
+  p.dHoWo = frmap_div_make((uint32_t)p.HoWo); p.dWo = frmap_div_make((uint32_t)Wi);
+  p.nchunks = Cin / 32;
+  p.ds_in = nullptr; p.ds_w = nullptr; p.ds_Hi = p.ds_Wi = p.ds_Cin = p.ds_stride = p.dsc = 0;
+  p.Wo2 = Wi / 2; p.dWo2 = frmap_div_make((uint32_t)p.Wo2);
+  int bn = Cout % 256 == 0 ? 256 : 128;
+  if (g_pp_bn == 128 || g_pp_bn == 256) bn = (g_pp_bn == 256 && Cout % 256) ? 128 : g_pp_bn;
+  int nhp = 0;
+  for (int attempt = 0; attempt < 2 && !nhp; ++attempt) {
+    const int tile_px = (bn == 256 ? 2 : 4) * 112;
+    const long long hbytes = (long long)pp_max_rows(Mll, tile_px, Hi * Wi, Wi, p.Hp, 3) * p.Wp * 64;
+    const int n = (int)((hbytes + 8191) / 8192);
+    if (hbytes / 64 < 65536 && n <= 5) { nhp = n; p.tile_px = tile_px; }
+    else bn = bn == 256 ? 128 : 256;   // the other layout (a wider tile has fewer halo rows per pixel, a narrower one fewer rows)
+    if (!nhp && Cout % bn) break;
+  }
+  if (!nhp) return 0;
+  p.mtiles = (int)((Mll + p.tile_px - 1) / p.tile_px); p.ntiles = Cout / bn;
+  if (!in) return 1;
+  int rc;
+#define PPP_GO(TT)                                                                                      \
+  (bn == 256 ? (nhp <= 3 ? pp_launch_pool<TT, 2, 3>(p, st) : pp_launch_pool<TT, 2, 5>(p, st))           \
+             : (nhp <= 3 ? pp_launch_pool<TT, 4, 3>(p, st) : pp_launch_pool<TT, 4, 5>(p, st)))
+  rc = dtype == FRMAP_BF16 ? PPP_GO(BF16) : PPP_GO(F16);
+#undef PPP_GO
+  return rc ? rc : 1;
+}
+
+extern "C" int frmap_conv3x3_pp_pool_layout(int B, int Hi, int Wi, int Cin, int Cout) {
+  if (B <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  return frmap_conv3x3_pp_pool(nullptr, nullptr, nullptr, nullptr, B, Hi, Wi, Cin, Cout, 0, FRMAP_BF16, nullptr);
 }
 
 extern "C" int frmap_conv3x3_pp_layout(int B, int Hi, int Wi, int Cin, int Cout) {

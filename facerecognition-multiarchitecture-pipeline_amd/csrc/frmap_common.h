@@ -274,6 +274,9 @@ int frmap_conv3x3_pp(const void* in, const void* w_packed, const float* shift, c
 // the same for 3x3 stride-2 pad-1 layers with even input sizes (conv3x3s2_pp_kernel)
 int frmap_conv3x3s2_pp(const void* in, const void* w_packed, const float* shift, const void* residual, void* out, int B, int Hi,
                        int Wi, int Cin, int Cout, int relu, int dtype, hipStream_t st);
+// conv3x3 s1 p1 + MaxPool2d(2, 2) on the same pipeline (conv3x3_pp_kernel<..., PL = true>)
+int frmap_conv3x3_pp_pool(const void* in, const void* w_packed, const float* shift, void* out, int B, int Hi, int Wi, int Cin,
+                          int Cout, int relu, int dtype, hipStream_t st);
 #define FRMAP_REQUIRE(cond, ...)        \
   do {                                  \
     if (!(cond)) {                      \

@@ -411,10 +411,8 @@ class SiameseNet(_HipModule):
             convs = convs[1:]
         else:
             x = self._as_nhwc4(x)
-        for conv, pool in convs:
-            x = conv(x, relu=True)
-            if pool:
-                x = ops.maxpool(x, 2, 2, 0)
+        for conv, pool in convs:     # conv -> BN -> ReLU (-> MaxPool2d(2)), `face_models.py:121-146`
+            x = conv.pooled(x) if pool else conv(x, relu=True)
         x = ops.avgpool_adaptive(x, 6, 6)  # NHWC B×6×6×512
         self.debug_shapes["after_conv"] = torch.Size((batch_size, 512, 6, 6))
         feats = x.view(batch_size, -1)

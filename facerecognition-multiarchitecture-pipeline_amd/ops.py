@@ -196,8 +196,20 @@ def conv_igemm(x: torch.Tensor, wpk: torch.Tensor, shift: torch.Tensor, Cout: in
     return out
 
 
+_pool2_cache: dict = {}
+
+
 def conv_pool2_supported(B: int, H: int, W: int, Cin: int, Cout: int) -> bool:
-    return bool(_lib.load().frmap_conv_igemm_pool2_supported(B, H, W, Cin, Cout))
+    """True when fusing the 2x2 max-pool into the conv is expected to win (see `frmap_conv_igemm_pool2_supported`)."""
+    key = (B, H, W, Cin, Cout)
+    if key not in _pool2_cache:
+        _pool2_cache[key] = bool(_lib.load().frmap_conv_igemm_pool2_supported(B, H, W, Cin, Cout))
+    return _pool2_cache[key]
+
+
+def conv_pool2_form(B: int, H: int, W: int, Cin: int, Cout: int) -> int:
+    """3 = ping-pong kernel, 2 = wave kernel, 1 = generic kernel, 0 = `conv_igemm_pool2` rejects the shape."""
+    return int(_lib.load().frmap_conv_igemm_pool2_form(B, H, W, Cin, Cout))
 
 
 def conv_igemm_pool2(x: torch.Tensor, wpk: torch.Tensor, shift: torch.Tensor, Cout: int, relu) -> torch.Tensor:

@@ -136,6 +136,11 @@ int frmap_conv_igemm(const void* in, const void* w_packed, const float* shift, c
  * Cin % 32 == 0, Cout % 64 == 0, the tile's input rows fit LDS); otherwise run frmap_conv_igemm +
  * frmap_maxpool. */
 int frmap_conv_igemm_pool2_supported(int B, int Hi, int Wi, int Cin, int Cout);
+/* which kernel frmap_conv_igemm_pool2 runs the shape on: 3 = LDS-DMA ping-pong kernel (row pairs tile a 112-pixel
+ * slice: Wi in {2,4,8,14,28,56}, Cin >= 128, Cout % 128 == 0), 2 = weights-resident wave kernel (Cin 32 / 64, Hi and Wi
+ * multiples of 8), 1 = generic kernel, 0 = not taken.  frmap_conv3x3_pp_pool_layout: 1 when the ping-pong form fits. */
+int frmap_conv_igemm_pool2_form(int B, int Hi, int Wi, int Cin, int Cout);
+int frmap_conv3x3_pp_pool_layout(int B, int Hi, int Wi, int Cin, int Cout);
 int frmap_conv_igemm_pool2(const void* in, const void* w_packed, const float* shift, void* out, int B, int Hi,
                            int Wi, int Cin, int Cout, int relu, int dtype, void* stream);
 

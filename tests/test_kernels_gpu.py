@@ -540,7 +540,12 @@ def test_conv_fused_maxpool2x2():
         (2, 112, 112, 32, 64, 1), (3, 56, 56, 64, 128, 1), (5, 6, 6, 64, 64, 1), (3, 12, 20, 32, 64, 0), (7, 2, 2, 32, 64, 1),
         (2, 56, 56, 128, 128, 1), (3, 28, 28, 256, 256, 1), (1, 4, 130, 32, 128, 1), (9, 14, 10, 96, 192, 1),
         (5, 8, 24, 32, 64, 1), (3, 16, 8, 64, 192, 0), (37, 8, 8, 64, 64, 1),   # 8-aligned maps with Cin 32 / 64: the wave-autonomous kernel
+        # row pairs that tile a 112-pixel slice, Cin >= 128, Cout % 128 == 0: the ping-pong kernel (both layouts, ragged tails,
+        # tiles straddling images, every admissible width)
+        (5, 14, 14, 128, 256, 1), (3, 8, 8, 128, 128, 1), (9, 4, 4, 256, 128, 0), (33, 2, 2, 128, 128, 1), (3, 28, 28, 160, 384, 1),
+        (1, 56, 56, 128, 256, 1), (7, 6, 14, 192, 128, 1),
     ]
+    forms = {0: 2, 1: 2, 5: 3, 6: 3, 2: 1, 12: 3, 13: 3, 15: 3}
     for ci, (B, H, W, Cin, Cout, relu) in enumerate(cases):
         for dtype in DTYPES:
             h = synth.randn(9700 + ci, (B, Cin, H, W), "h").to(dtype)
@@ -548,7 +553,7 @@ def test_conv_fused_maxpool2x2():
             shift = synth.randn(9720 + ci, (Cout,), "b") * 0.1
             ref = F.conv2d(h.float(), w.float(), None, padding=1) + shift.view(1, -1, 1, 1)
             ref = F.max_pool2d(F.relu(ref) if relu else ref, 2, 2)
-            assert ops.conv_pool2_supported(B, H, W, Cin, Cout), (ci, "not taken")
+            assert ops.conv_pool2_form(B, H, W, Cin, Cout) == forms.get(ci, ops.conv_pool2_form(B, H, W, Cin, Cout)) != 0, (ci, "form")
             x, wpk, sh = _nhwc(h).to(DEV), ops.pack_conv_weight(w.float().to(DEV), dtype), shift.to(DEV)
             y = ops.conv_igemm_pool2(x, wpk, sh, Cout, relu)
             y2 = ops.maxpool(ops.conv_igemm(x, wpk, sh, Cout, 3, 1, 1, relu), 2, 2, 0)
