@@ -211,6 +211,10 @@ def instrument(ops, torch, dt):
         G = 0 if gallery is None else gallery.shape[0]
         return f"gap_norm_match_kernel<{dt}>", 2.0 * B * C * G, _nbytes(fmap) + _nbytes(gallery) + 16 * B
 
+    def d_head(out, fmap, wt, scale, shift, eps=1e-12, want_pre=False):
+        B, H, W, K = fmap.shape
+        return f"gap_linear_norm_kernel<{dt}>", 2.0 * B * K * wt.shape[1], _nbytes(fmap) + _nbytes(wt) + _nbytes(out[0])
+
     def d_pool(out, x):
         return "avgpool_global_kernel", 0.0, _nbytes(x) + _nbytes(out)
 
@@ -225,7 +229,7 @@ def instrument(ops, torch, dt):
         return "match_top1 (gemm_nt_f32_kernel + finalize)", 2.0 * emb.shape[0] * emb.shape[1] * G, _nbytes(emb) + _nbytes(gallery) + 16 * emb.shape[0]
 
     for name, fn in (("conv_igemm", d_conv), ("conv_igemm_ds", d_conv_ds), ("stem7x7_maxpool", d_stem),
-                     ("stem7x7_maxpool_u8", d_stem_u8), ("gap_norm_match", d_gnm), ("avgpool_global", d_pool),
+                     ("stem7x7_maxpool_u8", d_stem_u8), ("gap_norm_match", d_gnm), ("gap_linear_norm", d_head), ("avgpool_global", d_pool),
                      ("linear_f32", d_lin), ("l2_normalize", d_l2), ("match_top1", d_match)):
         if hasattr(ops, name):
             wrap(name, fn)

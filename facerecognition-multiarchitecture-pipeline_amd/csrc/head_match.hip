@@ -497,6 +497,150 @@ extern "C" int frmap_gap_norm_match(const void* map, const float* gallery, float
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// ArcFaceNet head in one launch (face_models.py:573-590: `features(x).view(B,-1)` -> `self.embedding` (Linear, no bias)
+// -> `self.bn` (BatchNorm1d, eval) -> F.normalize): global average pool of the NHWC trunk map, y = (x . Wt) * scale +
+// shift, e = y / max(||y||, eps).  Replaces avgpool_global + linear_f32 + l2_normalize (three launches, 85 us at 1024
+// faces, the pooled features and the un-normalised embedding round-tripping through HBM).
+// One workgroup = FB faces: their pooled features sit in LDS as [K][FB] (one broadcast 16-byte read feeds 4 faces), thread t
+// owns outputs t, t + 256, ..: the K x N weight matrix is read TRANSPOSED ([K][N], row k = 4 N bytes, coalesced) once
+// per workgroup out of L2.
+// ------------------------------------------------------------------------------------------------
+template <typename TT, int FB, int NPT>
+__global__ __launch_bounds__(256) void gap_linear_norm_kernel(const typename TT::elem* __restrict__ map, const float* __restrict__ wt,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              float* __restrict__ pre_out, float* __restrict__ emb_out, float eps,
+                                                              int B, int HW, int K) {
+  constexpr int N = NPT * 256;
+  extern __shared__ float s_all[];
+  float* s_x = s_all;                 // [K][FB]
+  float* s_part = s_all + K * FB;     // [nparts][K] pooling partials of one face
+  float* s_red = s_part;              // (after the pooling) [FB][4] sums of squares
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b0 = blockIdx.x * FB;
+  const int C8 = K >> 3, nparts = C8 < 256 ? 256 / C8 : 1;
+  const float inv = 1.0f / (float)HW;
+  for (int f = 0; f < FB; ++f) {
+    const int b = min(b0 + f, B - 1);
+    const typename TT::elem* src = map + (size_t)b * HW * K;
+    auto pool_group = [&](int c8, int part) {   // rows part, part + nparts, .. of the 8-channel group c8, 8 loads in flight
+      float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int s0 = part; s0 < HW; s0 += 8 * nparts) {
+        u32x4_t r[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r[q] = *(const u32x4_t*)(src + (size_t)min(s0 + q * nparts, HW - 1) * K + c8 * 8);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          float v[8];
+          unpack8<TT>(r[q], v);
+          const float wq = s0 + q * nparts < HW ? 1.0f : 0.0f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a[j] = fmaf(wq, v[j], a[j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s_part[part * K + c8 * 8 + j] = a[j];
+    };
+    if (C8 < 256) {
+      if (tid < C8 * nparts) pool_group(tid % C8, tid / C8);
+    } else {
+      for (int c8 = tid; c8 < C8; c8 += 256) pool_group(c8, 0);
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += 256) {
+      float v = 0.f;
+      for (int q = 0; q < nparts; ++q) v += s_part[q * K + k];
+      s_x[k * FB + f] = v * inv;
+    }
+    __syncthreads();
+  }
+  // ---- y[f][n] = sum_k x[f][k] * wt[k][n]
+  float acc[NPT][FB];
+#pragma unroll
+  for (int j = 0; j < NPT; ++j)
+#pragma unroll
+    for (int f = 0; f < FB; ++f) acc[j][f] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 8) {
+    float w[8][NPT];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int j = 0; j < NPT; ++j) w[u][j] = wt[(size_t)(k0 + u) * N + j * 256 + tid];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      float x[FB];
+#pragma unroll
+      for (int f4 = 0; f4 < FB; f4 += 4) {
+        const f32x4_t v = *(const f32x4_t*)(s_x + (k0 + u) * FB + f4);
+        x[f4] = v[0]; x[f4 + 1] = v[1]; x[f4 + 2] = v[2]; x[f4 + 3] = v[3];
+      }
+#pragma unroll
+      for (int j = 0; j < NPT; ++j)
+#pragma unroll
+        for (int f = 0; f < FB; ++f) acc[j][f] = fmaf(x[f], w[u][j], acc[j][f]);
+    }
+  }
+  // ---- BatchNorm1d (folded to scale / shift), sum of squares per face, normalise
+  float ss[FB];
+#pragma unroll
+  for (int f = 0; f < FB; ++f) ss[f] = 0.f;
+#pragma unroll
+  for (int j = 0; j < NPT; ++j) {
+    const int n = j * 256 + tid;
+    const float sc = scale ? scale[n] : 1.f, sh = shift ? shift[n] : 0.f;
+#pragma unroll
+    for (int f = 0; f < FB; ++f) {
+      acc[j][f] = acc[j][f] * sc + sh;
+      ss[f] += acc[j][f] * acc[j][f];
+    }
+  }
+#pragma unroll
+  for (int f = 0; f < FB; ++f) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss[f] += __shfl_xor(ss[f], o, 64);
+  }
+  __syncthreads();   // (s_red aliases the pooling partials)
+  if (lane == 0) {
+#pragma unroll
+    for (int f = 0; f < FB; ++f) s_red[f * 4 + wave] = ss[f];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int f = 0; f < FB; ++f) {
+    if (b0 + f >= B) break;
+    const float denom = fmaxf(sqrtf(s_red[f * 4] + s_red[f * 4 + 1] + s_red[f * 4 + 2] + s_red[f * 4 + 3]), eps);
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+      const size_t o = (size_t)(b0 + f) * N + j * 256 + tid;
+      if (pre_out) pre_out[o] = acc[j][f];
+      if (emb_out) emb_out[o] = acc[j][f] / denom;
+    }
+  }
+}
+
+// wt: the Linear weight TRANSPOSED, fp32 [K][N] (N in {256, 512}); scale / shift: the folded BatchNorm1d ([N], may be NULL);
+// pre_out / emb_out: [B][N] fp32 un-normalised / unit-norm embeddings (either may be NULL)
+extern "C" int frmap_gap_linear_norm(const void* map, const float* wt, const float* scale, const float* shift, float* pre_out,
+                                     float* emb_out, float eps, int B, int HW, int K, int N, int dtype, void* stream) {
+  FRMAP_REQUIRE(map && wt && (pre_out || emb_out), "gap_linear_norm: null pointer");
+  FRMAP_REQUIRE(dtype == FRMAP_BF16 || dtype == FRMAP_F16, "gap_linear_norm: bad dtype");
+  FRMAP_REQUIRE(B > 0 && HW > 0 && K > 0 && K % 8 == 0 && K <= 2048, "gap_linear_norm: bad shape B=%d HW=%d K=%d", B, HW, K);
+  FRMAP_REQUIRE(N == 256 || N == 512, "gap_linear_norm: N=%d not supported (256 or 512)", N);
+  constexpr int FB = 8;
+  const int c8 = K / 8, nparts = c8 < 256 ? 256 / c8 : 1;
+  const size_t lds = (size_t)(K * FB + (nparts * K > FB * 4 ? nparts * K : FB * 4)) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((B + FB - 1) / FB);
+#define GLN_GO(TT, ET, NPT)                                                                                                  \
+  hipLaunchKernelGGL((gap_linear_norm_kernel<TT, FB, NPT>), grid, dim3(256), lds, st, (const ET*)map, wt, scale, shift, pre_out, \
+                     emb_out, eps, B, HW, K)
+  if (dtype == FRMAP_BF16) { if (N == 512) GLN_GO(BF16, __bf16, 2); else GLN_GO(BF16, __bf16, 1); }
+  else { if (N == 512) GLN_GO(F16, _Float16, 2); else GLN_GO(F16, _Float16, 1); }
+#undef GLN_GO
+  FRMAP_LAUNCH_CHECK();
+  return 0;
+}
+
 __global__ void argkey_finalize_kernel(const unsigned long long* __restrict__ keys, int32_t* __restrict__ out, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < B) out[b] = keys[b] ? (int32_t)(0xFFFFFFFFu - (unsigned)(keys[b] & 0xFFFFFFFFull)) : -1;

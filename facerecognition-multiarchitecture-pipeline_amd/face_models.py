@@ -52,6 +52,7 @@ def _bn_scale_shift(bn: nn.Module, bias: Optional[torch.Tensor] = None) -> Tuple
     return scale.contiguous(), shift.contiguous()
 
 
+_HEAD_FUSE = os.environ.get("FRMAP_HEAD_FUSE", "1") != "0"   # A/B switch: 0 = ArcFace head as avgpool + linear + normalize launches
 _POOL_FUSE = os.environ.get("FRMAP_POOL_FUSE", "1") != "0"   # A/B switch: 0 = conv and 2x2 max-pool as two launches
 
 
@@ -520,7 +521,8 @@ class ArcFaceNet(_HipModule):
 
     def _build_plan(self, dtype):
         scale, shift = _bn_scale_shift(self.bn)
-        return {"trunk": _TrunkPlan(self.backbone, dtype, self.input_mean, self.input_std), "bn_scale": scale, "bn_shift": shift}
+        return {"trunk": _TrunkPlan(self.backbone, dtype, self.input_mean, self.input_std), "bn_scale": scale, "bn_shift": shift,
+                "wt": self.embedding.weight.detach().float().t().contiguous()}   # [K][N] for the fused head
 
     def _pre_norm(self, x):
         p = self._get_plan()
@@ -529,6 +531,10 @@ class ArcFaceNet(_HipModule):
 
     def get_embedding(self, x):
         x = self._check_input(x)
+        p = self._get_plan()
+        if _HEAD_FUSE and p["wt"].shape[1] in (256, 512):
+            # avgpool + embedding + bn + F.normalize (`face_models.py:584-590`) in one launch
+            return ops.gap_linear_norm(p["trunk"].features(x), p["wt"], p["bn_scale"], p["bn_shift"], 1e-12)[0]
         return ops.l2_normalize(self._pre_norm(x), 1e-12)
 
     def forward(self, x, labels=None):

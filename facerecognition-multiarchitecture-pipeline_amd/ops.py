@@ -498,6 +498,26 @@ def match_top1(emb: torch.Tensor, gallery: torch.Tensor, thresh: Optional[float]
     return (idx, dist) if thresh is None else (idx, dist, ids)
 
 
+def gap_linear_norm(fmap: torch.Tensor, wt: torch.Tensor, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor],
+                    eps: float = 1e-12, want_pre: bool = False):
+    """ArcFaceNet head in one launch (`face_models.py:573-590`): global average pool of the NHWC trunk map [B,H,W,K] ->
+    Linear (``wt`` = weight transposed, fp32 [K][N]) -> folded BatchNorm1d -> L2-normalise.  Returns ``(emb, pre | None)``."""
+    fmap = _dev(fmap, "gap_linear_norm.map")
+    B, H, W, K = fmap.shape
+    wt = _dev(wt, "gap_linear_norm.wt", torch.float32)
+    if wt.dim() != 2 or wt.shape[0] != K or not wt.is_contiguous():
+        raise ValueError(f"gap_linear_norm: wt must be a contiguous [{K}][N] matrix")
+    N = int(wt.shape[1])
+    emb = torch.empty((B, N), dtype=torch.float32, device=fmap.device)
+    pre = torch.empty((B, N), dtype=torch.float32, device=fmap.device) if want_pre else None
+    _lib.check(_lib.load().frmap_gap_linear_norm(fmap.data_ptr(), wt.data_ptr(),
+                                                 _dev(scale, "scale", torch.float32).data_ptr() if scale is not None else 0,
+                                                 _dev(shift, "shift", torch.float32).data_ptr() if shift is not None else 0,
+                                                 pre.data_ptr() if pre is not None else 0, emb.data_ptr(), float(eps),
+                                                 B, H * W, K, N, dt_code(fmap.dtype), _stream()), "gap_linear_norm")
+    return emb, pre
+
+
 def gap_norm_match(fmap: torch.Tensor, gallery: torch.Tensor, thresh: Optional[float] = None, normalize: bool = False,
                    eps: float = 1e-12, want_emb: bool = False, packed: bool = False):
     """Global-average-pool an NHWC trunk map [B,H,W,C], optionally L2-normalise, and match against a small gallery

@@ -580,3 +580,25 @@ def test_conv_fused_maxpool2x2():
     with pytest.raises(ValueError):
         ops.conv_igemm_pool2(torch.zeros(1, 5, 6, 32, dtype=torch.bfloat16, device=DEV),
                              torch.zeros(64 * 32 * 9, dtype=torch.bfloat16, device=DEV), torch.zeros(64, device=DEV), 64, True)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_fused_arcface_head(dtype):
+    """`frmap_gap_linear_norm` (avgpool -> Linear(no bias) -> BatchNorm1d eval -> F.normalize, `face_models.py:573-590`) against
+    fp32 torch and against the three-launch path, ragged batch sizes (the kernel walks 8 faces per workgroup)."""
+    for ci, (B, H, W, K, N) in enumerate([(1, 7, 7, 512, 512), (19, 7, 7, 512, 512), (8, 3, 5, 256, 256), (33, 1, 1, 64, 512), (5, 14, 14, 2048, 256)]):
+        fmap = torch.relu(synth.randn(9800 + ci, (B, H, W, K), "m")).to(dtype)
+        w = synth.randn(9810 + ci, (N, K), "w") * (1.0 / math.sqrt(K))
+        scale = 1.0 + 0.1 * synth.randn(9820 + ci, (N,), "s")
+        shift = 0.1 * synth.randn(9830 + ci, (N,), "b")
+        pooled = fmap.float().mean(dim=(1, 2))
+        pre_ref = (pooled.double() @ w.double().t()).float() * scale + shift
+        emb_ref = F.normalize(pre_ref, p=2, dim=1, eps=1e-12)
+        emb, pre = ops.gap_linear_norm(fmap.to(DEV), w.t().contiguous().to(DEV), scale.to(DEV), shift.to(DEV), 1e-12, want_pre=True)
+        assert torch.allclose(pre.cpu(), pre_ref, atol=2e-5, rtol=2e-5), (ci, float((pre.cpu() - pre_ref).abs().max()))
+        assert torch.allclose(emb.cpu(), emb_ref, atol=2e-6, rtol=2e-5), (ci, float((emb.cpu() - emb_ref).abs().max()))
+        assert torch.allclose(emb.norm(dim=1).cpu(), torch.ones(B), atol=1e-5)
+        three = ops.l2_normalize(ops.linear_f32(ops.avgpool_global(fmap.to(DEV)), w.to(DEV), scale.to(DEV), shift.to(DEV)), 1e-12)
+        assert torch.allclose(emb, three, atol=2e-6, rtol=2e-5), (ci, "fused and three-launch heads differ")
+    with pytest.raises(ValueError):
+        ops.gap_linear_norm(torch.zeros(2, 7, 7, 512, dtype=dtype, device=DEV), torch.zeros(512, 384, device=DEV), None, None)
