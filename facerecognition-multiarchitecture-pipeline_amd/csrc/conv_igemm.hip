@@ -46,6 +46,11 @@ struct ConvParams {
   const void* ds_w;    // packed like a 1x1 conv: [Cout/64][ds_Cin/32][1][64][4][8]
   int ds_Hi, ds_Wi, ds_Cin, ds_stride, ds_chunks;
   FrmapPoolOrder pool;  // conv_igemm_kernel<..., POOL = true>: pool-major pixel order of the fused 2x2 max-pool
+  // conv1x1_kernel<..., MATCH = true>: the GEMM is probes x gallery rows, the epilogue keeps each probe's arg-min distance
+  const float* m_stat_a;           // [M][4] = (sum a^2, sum a, 1 / row scale, row scale) of the fp32 probes
+  const float* m_stat_w;           // [G][4] of the fp32 gallery rows
+  unsigned long long* m_keys;      // [M] packed (bits(d^2) << 32 | row), atomicMin
+  int m_G, m_D;                    // real gallery rows (Cout is padded to 64), embedding width
 };
 
 // 64 zero bytes: out-of-image (padding) pixels LOAD from here instead of branching around the load —
@@ -1005,7 +1010,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_fast_kernel(const ConvParams
 // 64 x 128 weights (16 KB) per stage, 64 MFMAs per wave per stage, both operands of the next stage
 // prefetched into registers under the current stage's MFMAs.  Split-K as in frmap_linear_mfma.
 // ================================================================================================
-template <typename TT, int CKS>
+// MATCH = true: top-1 gallery match (head_match.hip, frmap_match_top1_packed).  The "pixels" are the probes and the
+// "channels" the gallery rows, both split into fp16 (hi, lo) pairs laid out so that one K = 3 D GEMM accumulates
+// a_hi.g_hi + a_hi.g_lo + a_lo.g_hi in fp32 (= the fp32 dot product to ~2^-22); the epilogue forms the squared
+// F.pairwise_distance from it exactly as gemm_nt_f32_kernel<MODE_DIST> does and keeps one (distance, row) key per probe.
+template <typename TT, int CKS, bool MATCH = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const ConvParams p) {
   constexpr int BM = 256, MI = 4, NI = 4, NIT = BM * 4 / 256;
   using vec8 = typename TT::vec8;
@@ -1078,6 +1087,43 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const ConvParams p) {
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = TT::mfma(wf[ni], pf[mi], acc[mi][ni]);
     }
   }
+  if constexpr (MATCH) {
+    // lane: probe column lr of pixel group mi, gallery rows (nt * 64 + ni * 16 + 4 g + j): ascending row order inside the
+    // lane, strict < keeps the first minimum; the 4 lanes of a column meet through two shuffles; one atomic per probe
+    float w2[NI][4], ws[NI][4], wi[NI][4];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = min((nt << 6) + ni * 16 + 4 * g + j, p.m_G - 1);
+        const f32x4_t sw = *(const f32x4_t*)(p.m_stat_w + 4 * (size_t)n);
+        w2[ni][j] = sw[0]; ws[ni][j] = sw[1]; wi[ni][j] = sw[2];
+      }
+    const float eps = 1e-6f, keps = (float)p.m_D * eps * eps;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int b = m0 + wave * 64 + mi * 16 + lr;
+      const f32x4_t sa = *(const f32x4_t*)(p.m_stat_a + 4 * (size_t)min(b, p.M - 1));
+      const float a2 = sa[0], as = sa[1], ai = sa[2];
+      unsigned long long key = ~0ull;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = (nt << 6) + ni * 16 + 4 * g + j;
+          float d2 = a2 + w2[ni][j] - 2.f * (acc[mi][ni][j] * ai * wi[ni][j]) + 2.f * eps * (as - ws[ni][j]) + keps;
+          d2 = fmaxf(d2, 0.f);
+          const unsigned long long k2 = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)n;
+          if (n < p.m_G && k2 < key) key = k2;
+        }
+      unsigned long long o = __shfl_xor(key, 16, 64);
+      key = o < key ? o : key;
+      o = __shfl_xor(key, 32, 64);
+      key = o < key ? o : key;
+      if (g == 0 && b < p.M && key != ~0ull) atomicMin(p.m_keys + b, key);
+    }
+    return;
+  }
   __syncthreads();
   if (p.ksplit > 1)
     conv_epilogue_partial<MI, NI>(acc, smem + wave * (16 * (NI * 64 + 16)), m0 + wave * 64, p.M, p.Cout, nt << 6,
@@ -1087,9 +1133,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const ConvParams p) {
                               (const typename TT::elem*)p.res, (typename TT::elem*)p.out, p.relu, lane);
 }
 
-template <typename TT, int CKS>
+template <typename TT, int CKS, bool MATCH = false>
 static int launch_1x1(const ConvParams& p, hipStream_t st) {
-  auto kern = conv1x1_kernel<TT, CKS>;
+  auto kern = conv1x1_kernel<TT, CKS, MATCH>;
   if (frmap_big_lds((const void*)kern, 160 * 1024)) return -2;
   int lds = CKS * (256 * 64 + 4096);
   const int scratch = 4 * 16 * (4 * 64 + 16);
@@ -1433,6 +1479,33 @@ extern "C" int frmap_conv_igemm_pool2(const void* in, const void* w_packed, cons
   const int lds = p.halo_bytes + wbytes;
   if (BM == 256) return dtype == FRMAP_BF16 ? launch<BF16, 256, 3, 1, true>(p, lds, st) : launch<F16, 256, 3, 1, true>(p, lds, st);
   return dtype == FRMAP_BF16 ? launch<BF16, 128, 3, 1, true>(p, lds, st) : launch<F16, 128, 3, 1, true>(p, lds, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Top-1 match GEMM (frmap_match_top1_packed): probes3 = fp16 [B][3 D] rows (a_hi | a_hi | a_lo), gallery_packed = the
+// gallery's (g_hi | g_lo | g_hi) rows in conv-weight order (match_pack_gallery_kernel); every row carries its own
+// power-of-two scale, whose inverse is the third float of its statistics record.
+// ------------------------------------------------------------------------------------------------
+int frmap_match_gemm_f16x3(const void* probes3, const void* gallery_packed, const float* stat_a, const float* stat_w,
+                           unsigned long long* keys, int B, int G, int D, hipStream_t st) {
+  const int K3 = 3 * D, Gpad = (G + 63) / 64 * 64;
+  FRMAP_REQUIRE(K3 % 32 == 0, "match: D=%d must be a multiple of 32", D);
+  ConvParams p;
+  memset(&p, 0, sizeof(p));
+  p.in = probes3; p.wpk = gallery_packed;
+  p.N = B; p.Hi = 1; p.Wi = 1; p.Cin = K3; p.Ho = 1; p.Wo = 1; p.Cout = Gpad;
+  p.stride = 1; p.pad = 0;
+  p.M = B; p.HoWo = 1; p.Hp = 1; p.Wp = 1;
+  p.magic_Wp = frmap_magic(1u); p.magic_Hp = frmap_magic(1u);
+  p.dHoWo = frmap_div_make(1u); p.dWo = frmap_div_make(1u);
+  p.ksplit = 1;
+  p.nblocks = ((B + 255) / 256) * (Gpad / 64);
+  p.m_stat_a = stat_a; p.m_stat_w = stat_w; p.m_keys = keys; p.m_G = G; p.m_D = D;
+  const int c32 = K3 / 32;
+  if (c32 % 4 == 0) { p.nchunks = c32 / 4; return launch_1x1<F16, 4, true>(p, st); }
+  if (c32 % 2 == 0) { p.nchunks = c32 / 2; return launch_1x1<F16, 2, true>(p, st); }
+  p.nchunks = c32;
+  return launch_1x1<F16, 1, true>(p, st);
 }
 
 // ------------------------------------------------------------------------------------------------

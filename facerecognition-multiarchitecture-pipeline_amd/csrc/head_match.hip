@@ -36,6 +36,8 @@ struct GemmEpi {
   float* out;           // [B][N] or null
 };
 
+static inline int waves_blocks(int rows) { return (rows + 3) / 4; }
+
 __device__ __forceinline__ unsigned int f32_ordered(float f) {
   const unsigned int b = __float_as_uint(f);
   return (b & 0x80000000u) ? ~b : (b ^ 0x80000000u);
@@ -514,58 +516,67 @@ __global__ __launch_bounds__(256) void gap_linear_norm_kernel(const typename TT:
   constexpr int N = NPT * 256;
   extern __shared__ float s_all[];
   float* s_x = s_all;                 // [K][FB]
-  float* s_part = s_all + K * FB;     // [nparts][K] pooling partials of one face
-  float* s_red = s_part;              // (after the pooling) [FB][4] sums of squares
+  float* s_red = s_all + K * FB;      // [FB][4] sums of squares
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b0 = blockIdx.x * FB;
-  const int C8 = K >> 3, nparts = C8 < 256 ? 256 / C8 : 1;
+  const int C8 = K >> 3;
   const float inv = 1.0f / (float)HW;
-  for (int f = 0; f < FB; ++f) {
-    const int b = min(b0 + f, B - 1);
-    const typename TT::elem* src = map + (size_t)b * HW * K;
-    auto pool_group = [&](int c8, int part) {   // rows part, part + nparts, .. of the 8-channel group c8, 8 loads in flight
-      float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int s0 = part; s0 < HW; s0 += 8 * nparts) {
-        u32x4_t r[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) r[q] = *(const u32x4_t*)(src + (size_t)min(s0 + q * nparts, HW - 1) * K + c8 * 8);
+  // pooling: wave w takes faces w and w + 4 side by side (two independent accumulator sets: 16 loads of 16 bytes in flight
+  // per lane), lane l the 8-channel groups l, l + 64, ..; every lane walks all HW rows, so no partial sums meet in LDS
+  static_assert(FB == 8, "two faces per wave, four waves");
+  {
+    const int fa = wave, fb = wave + 4;
+    const typename TT::elem* sa = map + (size_t)min(b0 + fa, B - 1) * HW * K;
+    const typename TT::elem* sb = map + (size_t)min(b0 + fb, B - 1) * HW * K;
+    for (int c8 = lane; c8 < C8; c8 += 64) {
+      float a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int s0 = 0; s0 < HW; s0 += 8) {
+        u32x4_t ra[8], rb[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          float v[8];
-          unpack8<TT>(r[q], v);
-          const float wq = s0 + q * nparts < HW ? 1.0f : 0.0f;
+          const size_t o = (size_t)min(s0 + q, HW - 1) * K + c8 * 8;
+          ra[q] = *(const u32x4_t*)(sa + o);
+          rb[q] = *(const u32x4_t*)(sb + o);
+        }
 #pragma unroll
-          for (int j = 0; j < 8; ++j) a[j] = fmaf(wq, v[j], a[j]);
+        for (int q = 0; q < 8; ++q) {
+          float va[8], vb[8];
+          unpack8<TT>(ra[q], va);
+          unpack8<TT>(rb[q], vb);
+          const float wq = s0 + q < HW ? 1.0f : 0.0f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { a[j] = fmaf(wq, va[j], a[j]); c[j] = fmaf(wq, vb[j], c[j]); }
         }
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s_part[part * K + c8 * 8 + j] = a[j];
-    };
-    if (C8 < 256) {
-      if (tid < C8 * nparts) pool_group(tid % C8, tid / C8);
-    } else {
-      for (int c8 = tid; c8 < C8; c8 += 256) pool_group(c8, 0);
+      for (int j = 0; j < 8; ++j) {
+        s_x[(c8 * 8 + j) * FB + fa] = a[j] * inv;
+        s_x[(c8 * 8 + j) * FB + fb] = c[j] * inv;
+      }
     }
-    __syncthreads();
-    for (int k = tid; k < K; k += 256) {
-      float v = 0.f;
-      for (int q = 0; q < nparts; ++q) v += s_part[q * K + k];
-      s_x[k * FB + f] = v * inv;
-    }
-    __syncthreads();
   }
+  __syncthreads();
   // ---- y[f][n] = sum_k x[f][k] * wt[k][n]
   float acc[NPT][FB];
 #pragma unroll
   for (int j = 0; j < NPT; ++j)
 #pragma unroll
     for (int f = 0; f < FB; ++f) acc[j][f] = 0.f;
-  for (int k0 = 0; k0 < K; k0 += 8) {
-    float w[8][NPT];
+  // every workgroup reads the same K x N matrix: each starts at its own row block so that they do not all pull the same
+  // L2 lines at the same time
+  const int kstart = (int)(((long long)blockIdx.x * 40) % (K / 8)) * 8;
+  auto krow = [&](int it) { return it + kstart < K ? it + kstart : it + kstart - K; };
+  float wc[8][NPT], wn[8][NPT];
+  auto load_w = [&](float (&w)[8][NPT], int k0) {
 #pragma unroll
     for (int u = 0; u < 8; ++u)
 #pragma unroll
       for (int j = 0; j < NPT; ++j) w[u][j] = wt[(size_t)(k0 + u) * N + j * 256 + tid];
+  };
+  load_w(wc, krow(0));
+  for (int it = 0; it < K; it += 8) {   // the next 8 rows are requested before this block's FMAs (one L2 round trip per block otherwise)
+    const int k0 = krow(it);
+    load_w(wn, krow(it + 8 < K ? it + 8 : it));
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       float x[FB];
@@ -577,8 +588,12 @@ __global__ __launch_bounds__(256) void gap_linear_norm_kernel(const typename TT:
 #pragma unroll
       for (int j = 0; j < NPT; ++j)
 #pragma unroll
-        for (int f = 0; f < FB; ++f) acc[j][f] = fmaf(x[f], w[u][j], acc[j][f]);
+        for (int f = 0; f < FB; ++f) acc[j][f] = fmaf(x[f], wc[u][j], acc[j][f]);
     }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int j = 0; j < NPT; ++j) wc[u][j] = wn[u][j];
   }
   // ---- BatchNorm1d (folded to scale / shift), sum of squares per face, normalise
   float ss[FB];
@@ -599,7 +614,6 @@ __global__ __launch_bounds__(256) void gap_linear_norm_kernel(const typename TT:
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss[f] += __shfl_xor(ss[f], o, 64);
   }
-  __syncthreads();   // (s_red aliases the pooling partials)
   if (lane == 0) {
 #pragma unroll
     for (int f = 0; f < FB; ++f) s_red[f * 4 + wave] = ss[f];
@@ -627,10 +641,14 @@ extern "C" int frmap_gap_linear_norm(const void* map, const float* wt, const flo
   FRMAP_REQUIRE(B > 0 && HW > 0 && K > 0 && K % 8 == 0 && K <= 2048, "gap_linear_norm: bad shape B=%d HW=%d K=%d", B, HW, K);
   FRMAP_REQUIRE(N == 256 || N == 512, "gap_linear_norm: N=%d not supported (256 or 512)", N);
   constexpr int FB = 8;
-  const int c8 = K / 8, nparts = c8 < 256 ? 256 / c8 : 1;
-  const size_t lds = (size_t)(K * FB + (nparts * K > FB * 4 ? nparts * K : FB * 4)) * sizeof(float);
+  const size_t lds = (size_t)(K * FB + FB * 4) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((B + FB - 1) / FB);
+  {
+    const void* kerns[4] = {(const void*)gap_linear_norm_kernel<BF16, FB, 2>, (const void*)gap_linear_norm_kernel<BF16, FB, 1>,
+                            (const void*)gap_linear_norm_kernel<F16, FB, 2>, (const void*)gap_linear_norm_kernel<F16, FB, 1>};
+    if (frmap_big_lds(kerns[(dtype == FRMAP_BF16 ? 0 : 2) + (N == 512 ? 0 : 1)], 160 * 1024)) return -2;
+  }
 #define GLN_GO(TT, ET, NPT)                                                                                                  \
   hipLaunchKernelGGL((gap_linear_norm_kernel<TT, FB, NPT>), grid, dim3(256), lds, st, (const ET*)map, wt, scale, shift, pre_out, \
                      emb_out, eps, B, HW, K)
@@ -706,7 +724,6 @@ extern "C" size_t frmap_head_workspace_bytes(int B, int C) {
   return (size_t)16 * ((size_t)(B > 0 ? B : 0) + (size_t)(C > 0 ? C : 0)) + 256;
 }
 
-static inline int waves_blocks(int rows) { return (rows + 3) / 4; }
 
 extern "C" int frmap_linear_f32(const float* x, const float* w, const float* scale, const float* shift, float* out,
                                 int B, int K, int N, int relu, void* stream) {
@@ -767,6 +784,112 @@ extern "C" int frmap_match_top1(const float* emb, const float* gallery, int32_t*
     int rc = launch_gemm<MODE_DIST>(emb, gallery, B, G, D, ep, st);
     if (rc) return rc;
   }
+  hipLaunchKernelGGL(match_finalize_kernel, dim3(waves_blocks(B)), dim3(256), 0, st, emb, gallery, keys, idx_out, dist_out,
+                     id_or_unknown_out, packed_out, thresh, B, G, D);
+  FRMAP_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Large galleries on the MFMA pipe.  The fp32 GEMM above runs at ~60 TFLOP/s (fp32 MFMA peaks at 1/16 of the 16-bit
+// rate): at 1024 probes x 10 000 identities it is 175 us of a 4 ms step.  Here every fp32 operand x is split into two
+// fp16 numbers, hi = fp16(S x), lo = fp16(S x - hi) (S = 256 keeps lo out of the fp16 subnormals for |x| >= 2^-11), and
+// a.g ~ (a_hi.g_hi + a_hi.g_lo + a_lo.g_hi) / S^2, accumulated in fp32 by ONE K = 3 D GEMM on the 16x16x32 fp16 MFMA
+// (relative error ~2^-22, the size of the fp32 GEMM's own rounding).  The epilogue and the exact finalize step are those
+// of the fp32 path, so the result has the same contract: first minimum of the expanded distance, exact
+// F.pairwise_distance of the winner.  The gallery is split and laid out in the kernel's weight order ONCE per gallery.
+// ------------------------------------------------------------------------------------------------
+// Each row gets its own power-of-two scale S (largest |x| of the row lands in [2^13, 2^14): nothing overflows fp16, lo stays
+// out of the fp16 subnormals for every element within 2^-11 of the row maximum, and scaling by a power of two is exact);
+// statistics record of a row: (sum x^2, sum x, 1 / S, S).
+__device__ __forceinline__ float match_row_scale(float amax) {
+  if (!(amax > 0.f) || isinf(amax)) return 1.f;
+  int e;
+  frexpf(amax, &e);                 // amax = m * 2^e, m in [0.5, 1)
+  return ldexpf(1.f, 14 - e);       // amax * S in [2^13, 2^14)
+}
+
+// one wave per row: statistics + (probes) the split row (a_hi | a_hi | a_lo)
+__global__ void match_row_prep_kernel(const float* __restrict__ x, float* __restrict__ stat4, _Float16* __restrict__ split3,
+                                      int R, int D) {
+  const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const float* row = x + (size_t)r * D;
+  float s2 = 0.f, s1 = 0.f, amax = 0.f;
+  for (int k = lane; k < D; k += 64) {
+    const float v = row[k];
+    s2 += v * v; s1 += v; amax = fmaxf(amax, fabsf(v));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s2 += __shfl_xor(s2, o, 64); s1 += __shfl_xor(s1, o, 64); amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  }
+  const float S = match_row_scale(amax);
+  if (lane == 0) {
+    stat4[4 * (size_t)r] = s2; stat4[4 * (size_t)r + 1] = s1; stat4[4 * (size_t)r + 2] = 1.0f / S; stat4[4 * (size_t)r + 3] = S;
+  }
+  if (split3) {
+    _Float16* o = split3 + (size_t)r * 3 * D;
+    for (int k = lane; k < D; k += 64) {
+      const float v = row[k] * S;
+      const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+      o[k] = hi; o[D + k] = hi; o[2 * D + k] = lo;
+    }
+  }
+}
+
+__global__ void match_pack_gallery_kernel(const float* __restrict__ gal, const float* __restrict__ stat4, _Float16* __restrict__ out,
+                                          size_t total, int G, int D) {
+  const int nchunks = 3 * D / 32;
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; e < total; e += stride) {   // element order of frmap_pack_conv_weight for a 1x1 layer: [row/64][k/32][row%64][slot][8]
+    const int j = (int)(e & 7), slot = (int)((e >> 3) & 3), cl = (int)((e >> 5) & 63);
+    const size_t rest = e >> 11;
+    const int chunk = (int)(rest % nchunks), ntile = (int)(rest / nchunks);
+    const int cg = slot ^ (((cl >> 2) & 1) << 1);
+    const int k3 = chunk * 32 + cg * 8 + j, row = ntile * 64 + cl;
+    const int part = k3 / D, k = k3 - part * D;        // gallery side: (g_hi | g_lo | g_hi)
+    float v = 0.f;
+    if (row < G) v = gal[(size_t)row * D + k] * stat4[4 * (size_t)row + 3];
+    const _Float16 hi = (_Float16)v;
+    out[e] = part == 1 ? (_Float16)(v - (float)hi) : hi;
+  }
+}
+
+extern "C" size_t frmap_match_gallery_pack_bytes(int G, int D) {
+  if (G <= 0 || D <= 0) return 0;
+  return (size_t)((G + 63) / 64 * 64) * 3 * D * sizeof(_Float16);
+}
+
+// one-time preparation of a gallery for frmap_match_top1_packed: packed_out (frmap_match_gallery_pack_bytes), stat_w_out [G][4]
+extern "C" int frmap_match_pack_gallery(const float* gallery, void* packed_out, float* stat_w_out, int G, int D, void* stream) {
+  FRMAP_REQUIRE(gallery && packed_out && stat_w_out, "match_pack_gallery: null pointer");
+  FRMAP_REQUIRE(G > 0 && D > 0 && D % 32 == 0, "match_pack_gallery: bad shape G=%d D=%d (D %% 32 == 0)", G, D);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(match_row_prep_kernel, dim3(waves_blocks(G)), dim3(256), 0, st, gallery, stat_w_out, (_Float16*)nullptr, G, D);
+  const size_t total = (size_t)((G + 63) / 64 * 64) * 3 * D;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(match_pack_gallery_kernel, dim3(blocks), dim3(256), 0, st, gallery, (const float*)stat_w_out,
+                     (_Float16*)packed_out, total, G, D);
+  FRMAP_LAUNCH_CHECK();
+  return 0;
+}
+
+// frmap_match_top1 for a prepared gallery (same outputs, same contract).  workspace: frmap_head_workspace_bytes(B, 0) + 16 B
+// bytes; probe_split: B * 3 * D fp16 scratch.
+extern "C" int frmap_match_top1_packed(const float* emb, const float* gallery, const void* gallery_packed, const float* stat_w,
+                                       int32_t* idx_out, float* dist_out, int32_t* id_or_unknown_out, int32_t* packed_out,
+                                       float thresh, void* workspace, void* probe_split, int B, int G, int D, void* stream) {
+  FRMAP_REQUIRE(emb && gallery && gallery_packed && stat_w && idx_out && dist_out && workspace && probe_split, "match_top1_packed: null pointer");
+  FRMAP_REQUIRE(B > 0 && G > 0 && D > 0 && D % 32 == 0, "match_top1_packed: bad shape B=%d G=%d D=%d", B, G, D);
+  hipStream_t st = (hipStream_t)stream;
+  unsigned long long* keys = (unsigned long long*)workspace;
+  float* stat_a = (float*)(keys + B + (B & 1));   // [B][4], 16-byte aligned
+  hipLaunchKernelGGL(fill_u64_kernel, dim3((B + 255) / 256), dim3(256), 0, st, keys, B, ~0ull);
+  hipLaunchKernelGGL(match_row_prep_kernel, dim3(waves_blocks(B)), dim3(256), 0, st, emb, stat_a, (_Float16*)probe_split, B, D);
+  const int rc = frmap_match_gemm_f16x3(probe_split, gallery_packed, stat_a, stat_w, keys, B, G, D, st);
+  if (rc) return rc;
   hipLaunchKernelGGL(match_finalize_kernel, dim3(waves_blocks(B)), dim3(256), 0, st, emb, gallery, keys, idx_out, dist_out,
                      id_or_unknown_out, packed_out, thresh, B, G, D);
   FRMAP_LAUNCH_CHECK();

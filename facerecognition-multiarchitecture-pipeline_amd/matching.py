@@ -25,6 +25,7 @@ import torch
 
 from . import gallery_io, ops
 
+_MFMA_MATCH = os.environ.get("FRMAP_MATCH_MFMA", "1") != "0"   # A/B switch: 0 = large galleries on the fp32 GEMM
 REC_THRESH = 1.0                       # `app.py:20`
 REF_DIR = "face_references"            # `app.py:23`
 REF_FILE = os.path.join(REF_DIR, "face_references.pkl")   # `app.py:24`
@@ -42,6 +43,16 @@ class Gallery:
             raise ValueError("Gallery: need one D-vector per name")
         self.names = list(names)
         self.matrix = emb.to(device).contiguous()
+        self._pack = None
+
+    @property
+    def prepared(self):
+        """The gallery split for the MFMA match path (built on first use for galleries of >= `ops.MATCH_MFMA_MIN_G` rows)."""
+        if len(self.names) < ops.MATCH_MFMA_MIN_G or self.matrix.shape[1] % 32 or not _MFMA_MATCH:
+            return None
+        if self._pack is None or not self._pack.matches(self.matrix):
+            self._pack = ops.match_prepare(self.matrix)
+        return self._pack
 
     @classmethod
     def from_refs(cls, refs: Sequence[dict], device: Union[str, torch.device] = "cuda") -> "Gallery":
@@ -92,7 +103,7 @@ def _as_gallery(refs, device) -> Gallery:
 
 def match_batch(emb: torch.Tensor, gallery: Gallery) -> Tuple[torch.Tensor, torch.Tensor]:
     """B×D device embeddings → (int32[B] first-arg-min index, fp32[B] distance), on the device."""
-    return ops.match_top1(emb.to(torch.float32), gallery.matrix)
+    return ops.match_top1(emb.to(torch.float32), gallery.matrix, prepared=gallery.prepared)
 
 
 def get_embedding(face_img, model):
@@ -151,8 +162,8 @@ def embed_and_match(model, x: torch.Tensor, gallery, thresh: float = REC_THRESH,
         emb = ops.l2_normalize(emb, 1e-12)
     g = _as_gallery(gallery, emb.device)
     if packed is not None and packed is not False:
-        return ops.match_top1(emb.to(torch.float32), g.matrix, thresh, packed=packed)[3]
-    _idx, dist, ids = ops.match_top1(emb.to(torch.float32), g.matrix, thresh)
+        return ops.match_top1(emb.to(torch.float32), g.matrix, thresh, packed=packed, prepared=g.prepared)[3]
+    _idx, dist, ids = ops.match_top1(emb.to(torch.float32), g.matrix, thresh, prepared=g.prepared)
     return ids, dist
 
 

@@ -470,13 +470,62 @@ def _packed_buf(packed, B: int, device):
     return packed
 
 
-def match_top1(emb: torch.Tensor, gallery: torch.Tensor, thresh: Optional[float] = None, packed: bool = False):
+class MatchPack:
+    """A gallery prepared for the MFMA match path (`frmap_match_pack_gallery`): the fp32 rows split into fp16 (hi, lo)
+    pairs in the GEMM kernel's operand order, plus the per-row statistics of the expanded distance."""
+    __slots__ = ("packed", "stat_w", "G", "D", "src_ptr", "src_version")
+
+    def __init__(self, gallery: torch.Tensor):
+        gallery = _dev(gallery, "match_prepare.gallery", torch.float32)
+        self.G, self.D = int(gallery.shape[0]), int(gallery.shape[1])
+        lib = _lib.load()
+        self.packed = torch.empty((lib.frmap_match_gallery_pack_bytes(self.G, self.D),), dtype=torch.uint8, device=gallery.device)
+        self.stat_w = torch.empty((self.G, 4), dtype=torch.float32, device=gallery.device)
+        self.src_ptr, self.src_version = gallery.data_ptr(), gallery._version
+        _lib.check(lib.frmap_match_pack_gallery(gallery.data_ptr(), self.packed.data_ptr(), self.stat_w.data_ptr(), self.G, self.D,
+                                                _stream()), "match_pack_gallery")
+
+    def matches(self, gallery: torch.Tensor) -> bool:
+        return (gallery.data_ptr() == self.src_ptr and gallery._version == self.src_version and
+                tuple(gallery.shape) == (self.G, self.D) and gallery.device == self.packed.device)
+
+
+MATCH_MFMA_MIN_G = 512   # galleries at least this large take the MFMA path when a MatchPack is supplied
+
+
+@_on_operand_device
+def match_prepare(gallery: torch.Tensor) -> MatchPack:
+    return MatchPack(gallery)
+
+
+def match_top1(emb: torch.Tensor, gallery: torch.Tensor, thresh: Optional[float] = None, packed: bool = False,
+               prepared: Optional[MatchPack] = None):
     """First arg-min over gallery rows of ``||e - g + 1e-6||_2`` and that distance (int32[B], fp32[B]).
     With ``thresh`` a third tensor is returned: idx where dist <= thresh else -1 ("Unknown");
-    with ``packed`` a fourth: int32[B, 2] = (id-or-unknown, bits of dist), the all-gather record."""
+    with ``packed`` a fourth: int32[B, 2] = (id-or-unknown, bits of dist), the all-gather record.
+    ``prepared`` (`match_prepare(gallery)`): run the gallery scan on the fp16 MFMA pipe (same contract)."""
     emb = _dev(emb, "match_top1.emb", torch.float32)
     B, D = emb.shape
     G = int(gallery.shape[0]) if gallery is not None else 0
+    if prepared is not None and G >= MATCH_MFMA_MIN_G and D % 32 == 0:
+        gallery = _dev(gallery, "match_top1.gallery", torch.float32)
+        if not prepared.matches(gallery):
+            raise ValueError("match_top1: `prepared` was built from a different (or since modified) gallery")
+        idx = torch.empty((B,), dtype=torch.int32, device=emb.device)
+        dist = torch.empty((B,), dtype=torch.float32, device=emb.device)
+        ws = _workspace(2 * B + 2, 0, emb.device)     # keys [B] + per-probe statistics [B][4]
+        split = torch.empty((B, 3 * D), dtype=torch.float16, device=emb.device)
+        ids = torch.empty((B,), dtype=torch.int32, device=emb.device) if thresh is not None else None
+        pk = _packed_buf(packed, B, emb.device)
+        _lib.check(_lib.load().frmap_match_top1_packed(emb.data_ptr(), gallery.data_ptr(), prepared.packed.data_ptr(),
+                                                       prepared.stat_w.data_ptr(), idx.data_ptr(), dist.data_ptr(),
+                                                       ids.data_ptr() if ids is not None else 0,
+                                                       pk.data_ptr() if pk is not None else 0,
+                                                       float(thresh) if thresh is not None else float("inf"), ws.data_ptr(),
+                                                       split.data_ptr(), B, G, D, _stream()), "match_top1_packed")
+        if pk is not None:
+            return idx, dist, ids, pk
+        return (idx, dist) if thresh is None else (idx, dist, ids)
     gptr = 0
     if G > 0:
         gallery = _dev(gallery, "match_top1.gallery", torch.float32)
@@ -582,6 +631,6 @@ for _name in ("pack_input", "pack_conv_weight", "pack_conv_weight_c3", "conv_sma
               "conv_igemm_ds", "linear_mfma", "maxpool", "avgpool_global", "avgpool_adaptive", "linear_f32", "l2_normalize",
               "cast_to_f32", "cast_from_f32", "add_pos_layernorm", "mha_tokens", "mean_layernorm", "cnn_attention",
               "normalize_u8", "softmax_argmax", "pairwise_distance", "match_top1", "gap_norm_match", "cosine_logits",
-              "arcmargin_eval"):
+              "arcmargin_eval", "conv_small_cin_pool2", "conv_igemm_pool2", "gap_linear_norm"):
     globals()[_name] = _on_operand_device(globals()[_name])
 del _name

@@ -275,6 +275,19 @@ size_t frmap_head_workspace_bytes(int B, int C);
 int frmap_match_top1(const float* emb, const float* gallery, int32_t* idx_out, float* dist_out,
                      int32_t* id_or_unknown_out, int32_t* packed_out, float thresh, void* workspace,
                      int B, int G, int D, void* stream);
+/* The same match for LARGE galleries on the fp16 MFMA pipe (same outputs, same contract: first minimum of the
+ * expanded squared distance, exact F.pairwise_distance of the winner).  Every fp32 operand is split into two fp16
+ * numbers (hi = fp16(S x), lo = fp16(S x - hi)); one K = 3 D GEMM accumulates a_hi.g_hi + a_hi.g_lo + a_lo.g_hi in
+ * fp32 (the fp32 dot product to ~2^-22).  frmap_match_pack_gallery prepares a gallery ONCE: packed_out
+ * (frmap_match_gallery_pack_bytes(G, D) bytes) and stat_w_out [G][4]; D % 32 == 0.  Each row is scaled by its own power
+ * of two before the split, so any finite magnitude is safe.  frmap_match_top1_packed: workspace =
+ * frmap_head_workspace_bytes(2 * B + 2, 0) bytes, probe_split = B * 3 * D fp16 of scratch; `gallery` is still the fp32 matrix
+ * (the winner's exact distance is recomputed from it). */
+size_t frmap_match_gallery_pack_bytes(int G, int D);
+int frmap_match_pack_gallery(const float* gallery, void* packed_out, float* stat_w_out, int G, int D, void* stream);
+int frmap_match_top1_packed(const float* emb, const float* gallery, const void* gallery_packed, const float* stat_w,
+                            int32_t* idx_out, float* dist_out, int32_t* id_or_unknown_out, int32_t* packed_out,
+                            float thresh, void* workspace, void* probe_split, int B, int G, int D, void* stream);
 
 /* The tail of the ResNet-18 ('cnn') embed-and-match step for small galleries in ONE launch, one workgroup per face:
  * AdaptiveAvgPool2d(1) of the trunk map (face_models.py:100) -> optional F.normalize(eps) -> compare_faces' scan

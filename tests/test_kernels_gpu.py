@@ -602,3 +602,43 @@ def test_fused_arcface_head(dtype):
         assert torch.allclose(emb, three, atol=2e-6, rtol=2e-5), (ci, "fused and three-launch heads differ")
     with pytest.raises(ValueError):
         ops.gap_linear_norm(torch.zeros(2, 7, 7, 512, dtype=dtype, device=DEV), torch.zeros(512, 384, device=DEV), None, None)
+
+
+def test_match_top1_mfma_path_equals_fp32_path():
+    """Large galleries on the fp16 MFMA pipe (`frmap_match_top1_packed`: every fp32 operand split into a scaled fp16 (hi, lo)
+    pair, one K = 3 D GEMM) against the fp32-GEMM path and against the oracle-style exact scan: same winner, bit-identical
+    distance; ragged sizes, duplicate rows (first index wins), tiny and huge magnitudes, every stage width of the GEMM."""
+    def exact(e, g):
+        d = ((e[:, None, :].double() - g[None, :, :].double()) + 1e-6).pow(2).sum(-1).sqrt()
+        return d.min(dim=1)
+    for ci, (B, G, D, kind) in enumerate([(64, 1000, 512, "unit"), (1024, 10000, 512, "unit"), (37, 1001, 256, "unit"), (5, 777, 96, "unit"),
+                                          (130, 2049, 64, "big"), (16, 640, 512, "tiny"), (33, 1500, 128, "dup")]):
+        g = synth.unit_rows(9900 + ci, G, D, "gal")
+        e = synth.unit_rows(9910 + ci, B, D, "emb")
+        if kind == "big":
+            g, e = g * 3000.0, e * 2500.0
+        elif kind == "tiny":
+            g, e = g * 1e-3, e * 1e-3
+        elif kind == "dup":
+            g[700:740] = g[3]          # later copies of row 3: the first index must win
+            e[:8] = g[3] + 1e-4 * synth.randn(9920, (8, D), "n")
+        elif ci == 0:
+            e[:16] = g[100:116] + 5e-3 * synth.randn(9921, (16, D), "n")   # enrolment-style probes (near a gallery row)
+        gd, ed = g.to(DEV), e.to(DEV)
+        prep = ops.match_prepare(gd)
+        idx_m, dist_m, ids_m = ops.match_top1(ed, gd, 1.0, prepared=prep)
+        idx_f, dist_f, ids_f = ops.match_top1(ed, gd, 1.0)
+        assert torch.equal(idx_m, idx_f), (ci, int((idx_m != idx_f).sum()))
+        assert torch.equal(dist_m, dist_f) and torch.equal(ids_m, ids_f), ci
+        dmin, imin = exact(e, g)
+        agree = (idx_m.cpu().long() == imin)
+        # where the winner differs from the float64 scan it must be a tie at fp32 resolution
+        assert torch.allclose(dist_m.cpu().double()[~agree], dmin[~agree], rtol=2e-6, atol=1e-7), ci
+        assert float(agree.float().mean()) > 0.99, ci
+        if kind == "dup":
+            assert (idx_m[:8] == 3).all()
+    g = synth.unit_rows(1, 600, 512, "gal").to(DEV)
+    prep = ops.match_prepare(g)
+    g[0, 0] += 1.0     # in-place edit: the pack is stale and must be refused
+    with pytest.raises(ValueError):
+        ops.match_top1(synth.unit_rows(2, 4, 512, "e").to(DEV), g, 1.0, prepared=prep)
