@@ -110,9 +110,18 @@ __device__ __forceinline__ void pp_static_for(std::integer_sequence<int, Is...>,
 // pairs, its pixels are enumerated window by window (fragment row i of the slice = pixel i & 3 of window i >> 2), the
 // epilogue takes the max over each window's 4 transpose rows and writes the pooled map (conv_epilogue_pool2); SiameseNet
 // conv.7-10 / conv.14-17 (face_models.py:127-141).
-template <typename TT, int MI, int WM, int NHP, int KS, bool DS, bool IM = false, bool PL = false>
+// RI = true (plain layers): the fragment reads of k-step k + 1 ride BETWEEN the MFMAs of
+// MFMA(k) (a pixel fragment's registers are refilled right after its four MFMAs, the weight fragments are double-buffered)
+// instead of opening LOAD(k + 1) as one burst of 11 reads per wave: the LOAD segment shrinks to the DMA issue and the counted
+// wait, so a group's MFMA segment is what the other group waits for.  Measured before the change: LOAD alone 370 cycles,
+// MFMA alone 456, both together 620 per segment.  The reads of k + 1 now run one barrier interval EARLIER than the other
+// group's wait for its share of slab k + 1, so (KS = 1, shared buffers) slabs are issued three k-steps ahead into a ring of
+// five.  The per-tap fragment addresses are recomputed from 7 base registers (3 VALU each, under the MFMAs): hoisted, the
+// 63 of them spill.
+template <typename TT, int MI, int WM, int NHP, int KS, bool DS, bool IM = false, bool PL = false, bool RI = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
   static_assert(!(DS && KS == 2), "the fused shortcut is built for the pixel-split layouts only");
+  static_assert(!RI || (!DS && !IM), "the interleaved fragment reads are built for the plain layers");
   static_assert(!PL || (KS == 1 && !DS && !IM), "the pooled epilogue is built for the plain pixel-split layouts");
   static_assert(!(DS && IM), "the fused shortcut keeps its DMA in the LOAD segments");
   constexpr int NI = 4, WN = KS == 2 ? 2 : 8 / WM;
@@ -124,10 +133,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
   constexpr int TAPS = 9, BN = WN * 64, WB = BN * 64;      // slab bytes: BN channels x 32 channels x 2 B
   constexpr int GW = 8 / KS;                                 // waves that share one set of LDS buffers
   constexpr int NWI = (WB / 1024) / GW;                      // slab DMA instructions per wave and k-step (2, or 1 for BN = 128 / KS = 1)
-  constexpr int RING = 4;                                    // weight slabs in LDS (prefetch distance 2: a slab is rewritten
+  constexpr int RING = (RI && KS == 1) ? 5 : 4;              // weight slabs in LDS (prefetch distance 2: a slab is rewritten
                                                              // two full phases after the phase that last read it)
   constexpr int HB = NHP * GW * 1024;                        // bytes of one halo image buffer
   constexpr int GSZ = 2 * HB + RING * WB;                    // LDS of one buffer set: [halo 0][halo 1][slab 0 .. slab 3]
+  constexpr int PD = (RI && KS == 1) ? 3 : 2;                // slab prefetch distance (k-steps) of the non-IM forms
+  auto slot_of = [](int k) { return RING == 4 ? (k & 3) : k % RING; };
   using vec8 = typename TT::vec8;
   using elem = typename TT::elem;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -238,7 +249,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
   for (int j = 0; j < NHP; ++j) issue_halo(0, j);
   issue_slab(0, 0, 0);
   issue_slab(0, 1, 1);
-  if (IM) issue_slab(0, 2, 2);
+  if (IM || PD == 3) issue_slab(0, 2, 2);
 
   // fragment addressing
   int A[MI];  // (pixel index in the halo image) * 64 + k-group * 16, before the tap offset and the swizzle
@@ -282,7 +293,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
       // ---------------- LOAD(k): fragment reads first (their latency runs under the DMA issue and the barrier wait)
       vec8 wf[NI], pf[MI];
       {
-        const char* sl = slabs + (k & (RING - 1)) * WB;
+        const char* sl = slabs + slot_of(k) * WB;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) wf[ni] = *(const vec8*)(sl + ni * 1024);
         const int toff = ((t / 3) * p.Wp + (t % 3)) << 6;
@@ -299,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
         constexpr int XE = (DS && LAST && t > NHP) ? ((t - NHP - 1) * PPT < NGP ? (NGP - (t - NHP - 1) * PPT < PPT ? NGP - (t - NHP - 1) * PPT : PPT) : 0) : 0;
 #pragma unroll
         for (int e = 0; e < XE; ++e) issue_gather(1, (t - NHP - 1) * PPT + e);
-        issue_slab(t + 2 < TAPS ? ci : ci + 1, (t + 2) % TAPS, (k + 2) & (RING - 1));
+        issue_slab(t + 2 < TAPS ? ci : ci + 1, (t + 2) % TAPS, slot_of(k + 2));
         pp_wait_vm<NWI + (HP ? 1 : 0) + XE>();  // everything older than this phase's DMA has landed (slab k+1; next halo by t = 8)
         if (DS && LAST && t == TAPS - 1) pp_wait_lgkm0();  // (the first shortcut phase re-targets this chunk's halo buffer: retire its reads here)
       } else {
@@ -332,7 +343,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
                 const int cc = ci3 < nch ? ci3 : nch - 1;
                 const int chunk = KS == 2 ? grp + 2 * cc : cc;
                 const char* sp = wsrc + (size_t)(chunk * TAPS + (ci3 < nch ? (t + 3) % TAPS : TAPS - 1)) * 4096;
-                const unsigned dp = wdst + (unsigned)((k + 3) & (RING - 1)) * WB;
+                const unsigned dp = wdst + (unsigned)slot_of(k + 3) * WB;
                 if (idx == S0POS) pp_dma16(sp, dp);
                 else pp_dma16(sp + 1024, dp + 1024);
               }
@@ -343,7 +354,67 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
       pp_barrier();
     });
   };
-  if (DS) {
+  if constexpr (RI) {
+    // ---- fragment reads interleaved with the MFMAs (see the kernel comment).  Asw[mi][dx]: swizzled address of pixel
+    //      group mi at tap column dx; the tap row adds a multiple of 8 pixels (pitch % 8 == 0), which the swizzle ignores
+    auto frag_addr = [&](int mi, int toff) {   // 3 VALU under the MFMAs instead of 21 live registers
+      const int at = A[mi] + toff;
+      return at ^ ((at >> 3) & 32);
+    };
+    vec8 pf[MI], wf0[NI], wf1[NI];
+    {  // operands of k-step 0 (slab 0 and halo image 0 are in place: prologue wait + barrier)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wf0[ni] = *(const vec8*)(slabs + ni * 1024);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) pf[mi] = *(const vec8*)(halo + frag_addr(mi, 0));
+    }
+    // CP = parity of the chunk index: k = 9 ci + t alternates the two weight-fragment sets, so the nine-phase body exists
+    // once per parity and the chunk loop walks pairs
+    auto chunk_ri = [&](int ci, auto cp_c) {
+      constexpr int CP = decltype(cp_c)::value;
+      pp_static_for(std::make_integer_sequence<int, TAPS>{}, [&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int CUR = (CP + t) & 1;
+        const int k = ci * TAPS + t;
+        // ---------------- LOAD(k): this phase's DMA and the counted wait only
+        constexpr bool HP = t >= 1 && t <= NHP;
+        if (HP) issue_halo(ci + 1, t - 1);
+        issue_slab(t + PD < TAPS ? ci : ci + 1, (t + PD) % TAPS, slot_of(k + PD));
+        // only this phase's DMA stays in flight: slab k + 2 (issued one phase ago) has landed now, so after the NEXT barrier
+        // both groups' shares of it are visible - one whole interval before either group reads it (during its MFMA(k + 1))
+        pp_wait_vm<NWI + (HP ? 1 : 0)>();
+        pp_barrier();
+        // ---------------- MFMA(k), refilling the operand registers with k-step k + 1
+        pp_wait_lgkm0();
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int t1 = (t + 1) % TAPS;
+        const char* hb1 = halo + ((t == TAPS - 1 ? ci + 1 : ci) & 1) * HB;
+        const int toff1 = ((t1 / 3) * p.Wp + (t1 % 3)) << 6;
+        const char* sl1 = slabs + slot_of(k + 1) * WB;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) asm volatile("" : "+v"(A[mi]));   // keep the 7 base addresses, not 63 derived ones
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = TT::mfma(CUR ? wf1[ni] : wf0[ni], pf[mi], acc[mi][ni]);
+          __builtin_amdgcn_sched_barrier(0);
+          pf[mi] = *(const vec8*)(hb1 + frag_addr(mi, toff1));
+          if (mi < NI) {
+            if (CUR) wf0[mi] = *(const vec8*)(sl1 + mi * 1024);
+            else wf1[mi] = *(const vec8*)(sl1 + mi * 1024);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        pp_barrier();
+      });
+    };
+    int ci = 0;
+    for (; ci + 1 < nch; ci += 2) {
+      chunk_ri(ci, std::integral_constant<int, 0>{});
+      chunk_ri(ci + 1, std::integral_constant<int, 1>{});
+    }
+    if (ci < nch) chunk_ri(ci, std::integral_constant<int, 0>{});
+  } else if (DS) {
     for (int ci = 0; ci + 1 < nch; ++ci) chunk_body(ci, std::false_type{});
     chunk_body(nch - 1, std::true_type{});
   } else {
@@ -361,7 +432,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
       const int k = nk + d;
       vec8 wf[NI], pf[MI];
       {
-        const char* sl = slabs + (k & (RING - 1)) * WB;
+        const char* sl = slabs + slot_of(k) * WB;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) wf[ni] = *(const vec8*)(sl + ni * 1024);
         const char* gb = smem + gbuf(d);
@@ -370,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
       }
 #pragma unroll
       for (int e = 0; e < NGP; ++e) issue_gather(d + 2, e);
-      issue_slab(nch + (d + 2) / TAPS, (d + 2) % TAPS, (k + 2) & (RING - 1));
+      issue_slab(nch + (d + 2) / TAPS, (d + 2) % TAPS, slot_of(k + 2));
       pp_wait_vm<NWI + NGP>();
       pp_wait_lgkm0();   // retired before the barrier: the next phase's DMA re-targets the buffer image d - 1 ... d + 2 share
       pp_barrier();
@@ -638,6 +709,29 @@ extern "C" int frmap_conv_pp_tuning(int enable, int tile_px, int bn) {
 
 static int g_pp_im = -1;   // -1: environment FRMAP_PP_IM (default 0: measured 4-6 % SLOWER than issuing the DMA in the LOAD segments)
 extern "C" int frmap_conv_pp_im(int v) { g_pp_im = v; return 0; }
+static int g_pp_ri = -1;   // -1: environment FRMAP_PP_RI; 1: fragment reads interleaved with the MFMAs (RI = true) where the layout allows
+extern "C" int frmap_conv_pp_ri(int v) { g_pp_ri = v; return 0; }
+static bool pp_ri_on() {
+  static int env = -1;
+  if (env < 0) env = pp_env("FRMAP_PP_RI", 0);
+  return (g_pp_ri >= 0 ? g_pp_ri : env) != 0;
+}
+
+// RI = true launcher (plain layers): slab ring of 5 in the shared-buffer layouts
+template <typename TT, int MI, int WM, int NHP, int KS>
+static int pp_launch_ri(const PPParams& p, hipStream_t st) {
+  auto kern = conv3x3_pp_kernel<TT, MI, WM, NHP, KS, false, false, false, true>;
+  if (frmap_big_lds((const void*)kern, 160 * 1024)) return -2;
+  const int wb = (KS == 2 ? 2 : 8 / WM) * 64 * 64;
+  int lds = KS * (2 * NHP * (8 / KS) * 1024 + (KS == 1 ? 5 : 4) * wb);
+  const int scratch = 8 * 16 * (4 * 64 + 16);
+  const int xch = KS == 2 ? 4 * MI * 4 * 1024 : 0;
+  if (lds < scratch) lds = scratch;
+  if (lds < xch) lds = xch;
+  hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles), dim3(512), lds, st, p);
+  FRMAP_LAUNCH_CHECK();
+  return 0;
+}
 
 template <typename TT, int MI, int WM, int NHP, int KS, bool DS = false>
 static int pp_launch(const PPParams& p, hipStream_t st) {
@@ -690,6 +784,7 @@ int frmap_conv3x3_pp(const void* in, const void* w_packed, const float* shift, c
   if (pitch_env < 0) pitch_env = pp_env("FRMAP_PP_PITCH", 0);
   const bool wide_pitch = (g_pp_pitch >= 0 ? g_pp_pitch : pitch_env) != 0;
   if (wide_pitch) { while (p.Wp % 8 != Wi % 8) ++p.Wp; }
+  const bool ri_want = pp_ri_on() && ds == nullptr;   // RI form (plain layers): fragment reads under the MFMAs
   p.magic_Wp = frmap_magic((uint32_t)p.Wp); p.magic_Hp = frmap_magic((uint32_t)p.Hp);
   p.dHoWo = frmap_div_make((uint32_t)p.HoWo); p.dWo = frmap_div_make((uint32_t)Wi);
   p.nchunks = Cin / 32;
@@ -756,6 +851,15 @@ int frmap_conv3x3_pp(const void* in, const void* w_packed, const float* shift, c
              : pp_launch<TT, MI, 4, 5, 1, true>(p, st))
     rc = dtype == FRMAP_BF16 ? PPD_GO(BF16) : PPD_GO(F16);
 #undef PPD_GO
+    return rc ? rc : 1;
+  }
+  if (ri_want) {
+#define PPR_GO(TT)                                                                                              \
+  (ks == 2 ? (nhp <= 4 ? pp_launch_ri<TT, MI, 2, 4, 2>(p, st) : pp_launch_ri<TT, MI, 2, 6, 2>(p, st))            \
+   : bn == 256 ? (nhp <= 3 ? pp_launch_ri<TT, MI, 2, 3, 1>(p, st) : pp_launch_ri<TT, MI, 2, 5, 1>(p, st))        \
+               : (nhp <= 3 ? pp_launch_ri<TT, MI, 4, 3, 1>(p, st) : pp_launch_ri<TT, MI, 4, 5, 1>(p, st)))
+    rc = dtype == FRMAP_BF16 ? PPR_GO(BF16) : PPR_GO(F16);
+#undef PPR_GO
     return rc ? rc : 1;
   }
 #define PP_GO(TT)                                                                                               \

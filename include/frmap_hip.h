@@ -149,6 +149,10 @@ int frmap_conv_igemm_pool2(const void* in, const void* w_packed, const float* sh
  * channel tile (128 / 256; 1282 = 128 channels with the wave groups splitting K; -1 = heuristic).  Process-wide; not
  * needed for normal use. */
 int frmap_conv_pp_tuning(int enable, int tile_px, int bn);
+/* A/B hook of the second-generation kernel's fragment-read placement: 1 = reads of k-step k + 1 interleaved with the
+ * MFMAs of k-step k (conv3x3_pp_kernel<..., RI = true>) where the layout allows, 0 = one burst per phase, -1 = environment
+ * (FRMAP_PP_RI). */
+int frmap_conv_pp_ri(int v);
 /* Which layout frmap_conv_igemm gives a 3x3 stride-1 pad-1 layer without a fused shortcut: 0 = a first-generation
  * kernel; conv3x3_pp_kernel with 1 = 224 px x 256 ch tiles, 2 = 448 px x 128 ch, 3 = 224 px x 128 ch split-K. */
 int frmap_conv3x3_pp_layout(int B, int Hi, int Wi, int Cin, int Cout);

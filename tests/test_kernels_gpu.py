@@ -441,7 +441,10 @@ def test_conv_pp_kernel_shapes_and_tilings():
                 wpk = ops.pack_conv_weight(w.float().to(DEV), dtype)
                 xin, rin = _nhwc(x).to(DEV), (_nhwc(r).to(DEV) if res else None)
                 lib.frmap_conv_pp_tuning(1, px, bn)
+                lib.frmap_conv_pp_ri(0)
                 y_pp = ops.conv_igemm(xin, wpk, shift.to(DEV), Cout, 3, 1, 1, act, rin)
+                lib.frmap_conv_pp_ri(1)      # fragment reads interleaved with the MFMAs: same arithmetic, same order
+                y_ri = ops.conv_igemm(xin, wpk, shift.to(DEV), Cout, 3, 1, 1, act, rin)
                 lib.frmap_conv_pp_tuning(0, -1, -1)
                 y_g1 = ops.conv_igemm(xin, wpk, shift.to(DEV), Cout, 3, 1, 1, act, rin)
                 atol, rtol = _tol(dtype)
@@ -449,8 +452,10 @@ def test_conv_pp_kernel_shapes_and_tilings():
                 assert y.shape == ref.shape
                 assert torch.allclose(y, ref, atol=atol, rtol=rtol), (ci, dtype, float((y - ref).abs().max()))
                 assert torch.allclose(y_pp.float(), y_g1.float(), atol=atol, rtol=rtol), (ci, dtype, "generations differ")
+                assert torch.equal(y_ri, y_pp), (ci, dtype, "interleaved-read form differs", float((y_ri.float() - y_pp.float()).abs().max()))
     finally:
         lib.frmap_conv_pp_tuning(-1, -1, -1)
+        lib.frmap_conv_pp_ri(-1)
 
 
 def test_conv_pp_stride2_kernel():

@@ -16,7 +16,11 @@ def main():
     dev, dt = "cuda", torch.bfloat16
     # settings to compare, "bn[:im]": bn = -1 heuristic, 128, 256, 1282 (split-K), 0 = first generation; im = 1 / 0: DMA issued in
     # the MFMA segments (default) / in the LOAD segments
-    variants = [(int(v.split(":")[0]), int(v.split(":")[1]) if ":" in v else -1, int(v.split(":")[2]) if v.count(":") > 1 else -1) for v in a.variants.split(",")]
+    def _f(v, i, d=-1):
+        parts = v.split(":")
+        return int(parts[i]) if len(parts) > i else d
+    # "bn[:im[:pitch[:ri]]]"; ri = 1: fragment reads interleaved with the MFMAs (conv3x3_pp_kernel<..., RI = true>)
+    variants = [(_f(v, 0), _f(v, 1), _f(v, 2), _f(v, 3, 0)) for v in a.variants.split(",")]
     import ctypes
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name, H, C in (("l2 28x28 128", 28, 128), ("l3 14x14 256", 14, 256), ("l4 7x7 512", 7, 512)):
@@ -40,13 +44,14 @@ def main():
                 lib.frmap_conv_pp_tuning(a.pp if v[0] != 0 else 0, a.tile_px, v[0])
                 raw.frmap_conv_pp_im(v[1])
                 raw.frmap_conv_pp_pitch(v[2])
+                raw.frmap_conv_pp_ri(v[3])
                 for _ in range(3): run()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(a.reps): run()
                 e1.record(); torch.cuda.synchronize()
                 res[v].append(e0.elapsed_time(e1) / a.reps * 1e3)
-        print(f"{name:16s} " + "  ".join(f"bn{v[0]}/im{v[1]}/pitch{v[2]}: {min(t):6.1f} us ({fl / min(t) / 1e6:5.0f} TF)" for v, t in res.items()), flush=True)
+        print(f"{name:16s} " + "  ".join(f"bn{v[0]}/im{v[1]}/pitch{v[2]}/ri{v[3]}: {min(t):6.1f} us ({fl / min(t) / 1e6:5.0f} TF)" for v, t in res.items()), flush=True)
 
 if __name__ == "__main__":
     main()
