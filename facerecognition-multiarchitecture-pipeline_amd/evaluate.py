@@ -22,10 +22,15 @@ IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)     #
 FACENET_MEAN, FACENET_STD = (0.5, 0.5, 0.5), (0.5, 0.5, 0.5)                   # app.py:41
 
 
-def resize_to_u8(images: Sequence, size: Tuple[int, int] = (224, 224)) -> torch.Tensor:
-    """Host side of the transform: PIL images / HWC uint8 arrays → one uint8 [B, H, W, 3] tensor,
-    resized the way ``transforms.Resize(size)`` does for PIL input (bilinear)."""
+def resize_to_u8(images: Sequence, size: Tuple[int, int] = (224, 224), device=None) -> torch.Tensor:
+    """``transforms.Resize(size)`` for PIL input (bilinear): PIL images / HWC uint8 arrays → one uint8 [B, H, W, 3] tensor.
+    With ``device`` the decoded images are uploaded at their native size and resized on the GPU
+    (`resize.resize_bilinear_u8`, bit-exact with Pillow); without it Pillow does it on the host."""
     from PIL import Image
+    if device is not None:
+        from . import resize as _resize
+        return _resize.resize_bilinear_u8([np.asarray(im.convert("RGB") if isinstance(im, Image.Image) else im, np.uint8)
+                                           for im in images], size, device)
     out = np.empty((len(images), size[0], size[1], 3), np.uint8)
     for i, im in enumerate(images):
         if not isinstance(im, Image.Image):
@@ -95,7 +100,7 @@ def _folder_batches(samples, batch_size, device):
         for path, _ in chunk:
             with Image.open(path) as im:
                 imgs.append(im.convert("RGB"))
-        u8 = resize_to_u8(imgs, (224, 224))                                   # transforms.Resize((224, 224)), `testing.py:100`
+        u8 = resize_to_u8(imgs, (224, 224), device=device)                    # transforms.Resize((224, 224)), `testing.py:100`: on the device
         yield preprocess(u8, IMAGENET_MEAN, IMAGENET_STD, device), torch.tensor([c for _, c in chunk], dtype=torch.int64)
 
 

@@ -109,16 +109,15 @@ def match_batch(emb: torch.Tensor, gallery: Gallery) -> Tuple[torch.Tensor, torc
 def get_embedding(face_img, model):
     """`app.py:32-48`: BGR uint8 crop → RGB → Resize((160,160)) → ToTensor → Normalize(0.5, 0.5) →
     ``model(x)`` on the model's device under ``no_grad``; ``None`` for an empty crop or on ANY
-    exception (the reference swallows them, `:46-48`).  The resize is PIL's (host), the
-    uint8 → normalised-float step and the model run on the GPU."""
+    exception (the reference swallows them, `:46-48`).  The crop is uploaded as it is; the resize (bit-exact with
+    PIL's, `resize.resize_bilinear_u8`), the uint8 → normalised-float step and the model run on the GPU."""
     if face_img is None or getattr(face_img, "size", 0) == 0:
         return None
     try:
-        from PIL import Image
+        from . import resize as _resize
         rgb = np.ascontiguousarray(np.asarray(face_img)[:, :, ::-1])
-        pil = Image.fromarray(rgb).resize((160, 160), Image.BILINEAR)
         dev = next(model.parameters()).device
-        u8 = torch.from_numpy(np.array(pil, np.uint8)).unsqueeze(0).to(dev)
+        u8 = _resize.resize_bilinear_u8([rgb], (160, 160), dev)
         x = ops.normalize_u8(u8, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))[0]
         with torch.no_grad():
             return model(x)

@@ -54,6 +54,18 @@ int frmap_pack_input_nchw_f32(const float* x_nchw, void* out_nhwc4, int B, int H
 int frmap_normalize_u8_hwc(const unsigned char* img_u8, float* out_nchw_f32, void* out_nhwc4, int B, int H,
                            int W, const float* mean3_host, const float* std3_host, int dtype, void* stream);
 
+/* `transforms.Resize((H, W))` for PIL-style 8-bit RGB images (src/testing.py:99-100, 561-566; src/training.py:305-310;
+ * src/app.py:39), batched, bit-exact with Pillow's two-pass bilinear resampler (libImaging/Resample.c: integer FIR taps
+ * with 22 fractional bits, the horizontal pass rounded to 8 bits before the vertical pass).  src_pool: the images' bytes
+ * (HWC uint8 RGB, native sizes) back to back; items: B records
+ *     struct { uint64 src_off; int32 H, W, bx_off, kx_off, ksx, by_off, ky_off, ksy; }      (40 bytes, device memory)
+ * with offsets (int32 elements) into `tables` of the per-axis bounds [out][2] = (first input sample, taps) and coefficients
+ * [out][ks] (ks = 0: that axis keeps its size) - built by the host in float64 with Pillow's operation order
+ * (resize.py:bilinear_coeffs).  out: B x out_h x out_w x 3 uint8.  One workgroup resizes rows_per_block output rows;
+ * lds_rows = the most input rows one workgroup touches (lds_rows * out_w * 4 bytes of LDS). */
+int frmap_resize_bilinear_u8(const unsigned char* src_pool, const void* items, const int* tables, unsigned char* out,
+                             int B, int out_h, int out_w, int rows_per_block, int lds_rows, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Conv weight packing.  `w_oihw` = fp32 [Cout][Cin][KH][KW] with the BatchNorm scale already
  * folded in (w * gamma/sqrt(var+eps)); output is the kernel's LDS-image order in `dtype`.

@@ -324,3 +324,29 @@ def test_uint8_input_stem_is_bit_identical_to_normalize_then_fp32_path(dtype, ca
         assert torch.equal(m.get_embedding(x8[:2]), m.get_embedding(evaluate.preprocess(x8[:2], evaluate.FACENET_MEAN, evaluate.FACENET_STD)))
     with pytest.raises(ValueError):
         m(torch.zeros((2, 3, 224, 224), dtype=torch.uint8, device=DEV))    # uint8 must be HWC
+
+
+def test_device_resize_is_bit_exact_with_pillow(tmp_path):
+    """`frmap_resize_bilinear_u8` (`transforms.Resize((224, 224))` of `src/testing.py:99-100` on the device)
+    against Pillow, bit for bit: a ragged batch of images of different sizes in ONE launch (up- and down-scaling, one axis
+    unchanged, same size, 1x1, a 20x reduction), the 160x160 target of `src/app.py:39`, and the evaluation harness's
+    batches (decoded files -> device resize -> normalise) against the host path."""
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image
+    from frmap_amd import evaluate, resize
+    rng = np.random.default_rng(11)
+    shapes = [(224, 224), (300, 400), (112, 112), (1, 1), (2, 3), (500, 37), (37, 500), (225, 223), (900, 1000), (224, 100), (223, 224),
+              (4480, 30), (640, 480), (480, 640), (131, 977)]
+    imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in shapes]
+    for (oh, ow) in [(224, 224), (160, 160), (96, 128)]:
+        got = resize.resize_bilinear_u8(imgs, (oh, ow), "cuda").cpu().numpy()
+        for i, a in enumerate(imgs):
+            ref = np.asarray(Image.fromarray(a).resize((ow, oh), Image.BILINEAR))
+            assert np.array_equal(got[i], ref), (shapes[i], oh, ow, int(np.abs(got[i].astype(int) - ref.astype(int)).max()))
+    pil = [Image.fromarray(a) for a in imgs[:6]]
+    host = evaluate.resize_to_u8(pil, (224, 224))
+    dev = evaluate.resize_to_u8(pil, (224, 224), device="cuda")
+    assert dev.is_cuda and torch.equal(dev.cpu(), host)
+    assert resize.resize_bilinear_u8([], (224, 224), "cuda").shape == (0, 224, 224, 3)
+    with pytest.raises(ValueError):
+        resize.resize_bilinear_u8([np.zeros((4, 4), np.uint8)], (224, 224), "cuda")
