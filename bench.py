@@ -323,7 +323,8 @@ def worker(args) -> int:
     model_type = args.model or ("arcface" if cfg_multi else "cnn")
     B = args.batch or (1024 if cfg_multi else 256)
     G = args.gallery or (10000 if cfg_multi else 36)
-    seeds = {"cnn": (1002, 2002, 3002), "arcface": (1004, 2004, 3004)}.get(model_type, (1002, 2002, 3002))
+    seeds = {"cnn": (1002, 2002, 3002), "arcface": (1004, 2004, 3004), "baseline": (1001, 2001, 3001), "siamese": (1006, 2006, 3006),
+             "hybrid": (1005, 2005, 3005), "attention": (1007, 2007, 3007)}.get(model_type, (1002, 2002, 3002))
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     D = 256 if model_type == "siamese" else 512
 

@@ -21,7 +21,7 @@ import frmap_amd  # noqa: E402
 import frmap_amd.synth as synth  # noqa: E402
 from oracle import weights  # noqa: E402
 
-PAIRS = [("cnn", weights.SEEDS["cnn"][0]), ("arcface", weights.SEEDS["arcface"][0])]
+PAIRS = [(mt, weights.SEEDS[mt][0]) for mt in ("cnn", "arcface", "baseline", "siamese", "hybrid", "attention") if mt in weights.SEEDS]
 
 
 def main():
