@@ -268,8 +268,10 @@ def stored_traffic():
             for k, v in kernels.items():
                 if not k.startswith(head):
                     continue
-                if want_ds is not None and k.startswith("conv3x3_pp_kernel<") and (k.rstrip(">").split(", ")[-2] == "true") != want_ds:
-                    continue
+                if want_ds is not None and k.startswith("conv3x3_pp_kernel<"):
+                    targs = k[k.index("<") + 1:].rstrip(">").split(", ")     # <T, MI, WM, NHP, KS, DS, IM[, PL, RI]>
+                    if (len(targs) > 5 and targs[5] == "true") != want_ds:
+                        continue
                 c = max(v.get("launches_FETCH_SIZE", 0), 1)
                 tot += v["hbm_bytes_per_launch"] * c
                 n += c
