@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256, 2) void conv_small_cin_kernel(const SmallCinPa
   constexpr int KTOT = KH * KR;
   constexpr int KPAD = (KTOT + 31) / 32 * 32;
   constexpr int KSTEPS = KPAD / 32;
-  constexpr int WPITCH = (KPAD + 8) * 2;  // bytes per output channel in the weight image
+  constexpr int WPITCH = (KPAD + 16) * 2;  // bytes per output channel in the weight image: 160 / 480 B keep the ds_read_b128 of a
+                                           // lane group (16 channels x this k-group + its neighbours) on distinct banks (144 / 464 B: 2-way)
   constexpr int COUT = NI * 16;
   using vec8 = typename TT::vec8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_cin_kernel(const SmallCinPa
   const int rr0 = oy0 * STRIDE;
   const int nrows = (n1 - n0) * p.Hp + oy1 * STRIDE - rr0 + KH;
 
-  // ---- stage weights (whole [COUT][KPAD+8] image, already in this order in global) -------------
+  // ---- stage weights (whole [COUT][KPAD+16] image, already in this order in global) -------------
   {
     const u32x4_t* src = (const u32x4_t*)p.wpk;
     constexpr int NV = COUT * WPITCH / 16;
@@ -183,7 +184,7 @@ static int small_rows_bound(int BM, int Ho, int Wo, int Hp, int stride, int KH) 
 
 extern "C" int frmap_small_cin_kpad(int KH, int KW) {
   const int kr = (KW * 4 > 16) ? 32 : 16;
-  return (KH * kr + 31) / 32 * 32 + 8;
+  return (KH * kr + 31) / 32 * 32 + 16;
 }
 
 static int small_pool_rows_bound(int BM, int Ho, int Wo, int Hp, int KH) {
@@ -197,7 +198,7 @@ template <typename TT, int NI, int KH, int KW, int STRIDE, bool POOL = false>
 static int launch_small(SmallCinParams& p, hipStream_t st) {
   constexpr int KR = (KW * 4 > 16) ? 32 : 16;
   constexpr int KPAD = (KH * KR + 31) / 32 * 32;
-  const int wbytes = NI * 16 * (KPAD + 8) * 2;
+  const int wbytes = NI * 16 * (KPAD + 16) * 2;
   long long hb = (long long)(POOL ? small_pool_rows_bound(256, p.Ho, p.Wo, p.Hp, KH) : small_rows_bound(256, p.Ho, p.Wo, p.Hp, STRIDE, KH)) * p.Wl * 8;
   hb = (hb + 1023) & ~1023ll;
   FRMAP_REQUIRE(hb + wbytes <= 160 * 1024, "conv_small_cin: rows too wide for LDS (W=%d)", p.Wi);

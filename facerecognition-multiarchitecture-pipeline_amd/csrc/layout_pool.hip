@@ -102,7 +102,7 @@ extern "C" int frmap_pack_conv_weight(const float* w, void* out, int Cout, int C
   return 0;
 }
 
-// first-layer (Cin=3) weights: [Cout][KPAD+8], k = kh*KR + kw*4 + c, zeros elsewhere
+// first-layer (Cin=3) weights: [Cout][KPAD+16], k = kh*KR + kw*4 + c, zeros elsewhere
 template <typename TT>
 __global__ void pack_conv_weight_c3_kernel(const float* __restrict__ w, typename TT::elem* __restrict__ out, int Cout,
                                            int KH, int KW, int KR, int pitch) {

@@ -65,7 +65,7 @@ __device__ __forceinline__ float row_down(float v) {
 // fp32 path - the 256-register budget then spills ~15 - and NIT x 3 in the uint8 path).
 template <typename TT, bool POOL3, bool VEC4, bool U8, bool PF>
 __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams p) {
-  constexpr int MI = POOL3 ? 7 : 6, NI = 4, KSTEPS = 7, KPAD = 224, WPITCH = (KPAD + 8) * 2;
+  constexpr int MI = POOL3 ? 7 : 6, NI = 4, KSTEPS = 7, KPAD = 224, WPITCH = (KPAD + 16) * 2;
   constexpr int PADL0 = POOL3 ? 5 : 3, NROWS = 2 * (MI - 1) + 7;
   // VEC4: 4-pixel groups start on multiples of 4 input columns (colbase - (PADL - 1) + 4q) and land at image pixel
   // 4q + 1: the image origin stays an EVEN number of pixels left of the scalar path's, so fragment reads stay 16-byte aligned
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
   }
   if (tile >= t_hi) return;
 
-  {  // weights: [64][232] image (same packing as conv_small_cin), resident for the whole kernel
+  {  // weights: [64][240] image (same packing as conv_small_cin), resident for the whole kernel
     const u32x4_t* src = (const u32x4_t*)p.wpk;
     constexpr int NV = 64 * WPITCH / 16;
     for (int i = tid; i < NV; i += 256) ((u32x4_t*)wl)[i] = src[i];
@@ -353,7 +353,7 @@ static int stem_launch(const float* x_nchw, const unsigned char* x_u8, const flo
   const int wlh = vec4 ? 4 * (pool3 ? 32 : 35) + 2 : p.Wl;  // must mirror the kernel's WLH
   const int hb = (nrows * wlh * 8 + 1023) & ~1023;
   p.halo_bytes = hb;
-  const int wbytes = 64 * 232 * 2;
+  const int wbytes = 64 * 240 * 2;
   const int scratch = 4 * 16 * (4 * 64 + 16);
   const int lds = hb + wbytes + scratch + 3 * 256 * 2;  // + the uint8 normalisation table
   static int ncu = 0;
