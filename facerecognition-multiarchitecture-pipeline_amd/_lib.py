@@ -45,6 +45,7 @@ PROTOTYPES = {
     "frmap_conv_igemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "frmap_conv_pp_tuning": (_i, [_i, _i, _i]),
     "frmap_conv_pp_ri": (_i, [_i]),
+    "frmap_conv1x1_pp_layout": (_i, [_i, _i, _i, _i, _i, _i]),
     "frmap_conv3x3_pp_layout": (_i, [_i, _i, _i, _i, _i]),
     "frmap_conv3x3s2_pp_layout": (_i, [_i, _i, _i, _i, _i]),
     "frmap_conv3x3_pp_ds_layout": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),

@@ -1261,7 +1261,13 @@ static int conv_igemm_impl(const void* in, const void* w_packed, const float* sh
     const int BM = 256;
     p.halo_bytes = BM * 64;
     p.nblocks = ((p.M + BM - 1) / BM) * ntiles;
-    if (p.dbg == 0 && Cin >= 128) return dispatch_1x1(p, dtype, st);  // wide stages pay once there are several of them
+    if (p.dbg == 0 && Cin >= 128) {
+      // wide layers: the LDS-DMA ping-pong pipeline when it has enough tiles (conv_pp.hip)
+      const int rc = frmap_conv1x1_pp(in, w_packed, shift, residual, out, B, Hi, Wi, Cin, Cout, stride, relu, dtype, st);
+      if (rc < 0) return rc;
+      if (rc == 1) return 0;
+      return dispatch_1x1(p, dtype, st);  // wide stages pay once there are several of them
+    }
     const int lds = p.halo_bytes + wbytes;
     return dtype == FRMAP_BF16 ? launch<BF16, 256, 1, 1>(p, lds, st) : launch<F16, 256, 1, 1>(p, lds, st);
   }

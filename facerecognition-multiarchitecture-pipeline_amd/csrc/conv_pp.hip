@@ -490,6 +490,150 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
 }
 
 // ================================================================================================
+// 1x1 convolutions and wide Linear layers on the same pipeline (the fused-shortcut phases of conv3x3_pp_kernel on their
+// own): one k-step = one 32-channel slice; its pixel operand is a GATHER image of the tile's own pixels (64 B each, DMA'd from
+// (oy * s, ox * s) of the NHWC input: any stride, no halo) in a ring of three buffers, its weight operand a BN x 32 slab in a
+// ring of four; image and slab k + 2 are issued in phase k, a phase retires its fragment reads BEFORE its barrier (the next
+// phase's DMA re-targets the buffer image k - 1 used), the two wave groups run half a phase apart.  Against conv1x1_kernel
+// (conv_igemm.hip: 256 px x 64 ch tiles staged through registers, bound by the VGPR -> LDS write rate) a tile here is 224 px x
+// 256 ch or 448 px x 128 ch: a quarter / half of the pixel bytes per MFMA, none of them through registers.
+// KS = 2: 224 px x 128 ch with the two wave groups splitting K (own buffers; accumulators merged through LDS) for outputs with
+// few tiles (Linear 2048 -> 512 over 12 544 tokens: 224 tiles instead of 112).
+// ================================================================================================
+template <typename TT, int MI, int WM, int KS>
+__global__ __launch_bounds__(512, 2) void conv1x1_pp_kernel(const PPParams p) {
+  constexpr int NI = 4, WN = KS == 2 ? 2 : 8 / WM;
+  constexpr int CAP = (KS == 2 ? 2 : WM) * MI * 16;          // pixels of a tile
+  constexpr int BN = WN * 64, WB = BN * 64;
+  constexpr int GW = 8 / KS;                                 // waves that share one set of LDS buffers
+  constexpr int NWI = (WB / 1024) / GW;                      // slab DMA instructions per wave and k-step
+  constexpr int NGP = (CAP / 16 + GW - 1) / GW;              // gather pieces (16 pixels = 1 KB) per wave and image
+  constexpr int IMGB = NGP * GW * 1024;                      // bytes of one gather image buffer
+  constexpr int RING = 4;
+  constexpr int GSZ = 3 * IMGB + RING * WB;                  // LDS of one buffer set: [image 0..2][slab 0..3]
+  using vec8 = typename TT::vec8;
+  using elem = typename TT::elem;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, q = wave & 3;
+  const int gw = KS == 2 ? q : wave;
+  const int wn = (KS == 2 || WM == 4) ? (wave & 1) : q;
+  const int mslice = KS == 2 ? (q >> 1) : (WM == 2 ? grp : grp * 2 + (q >> 1));
+  const int gbase = KS == 2 ? grp * GSZ : 0;
+  const int lr = lane & 15, g = lane >> 4;
+
+  const int L = pp_xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = L / p.ntiles, nt = L - mt * p.ntiles;
+  const int m0 = mt * p.tile_px, mend = min(m0 + p.tile_px, p.M);
+  const int nst = p.nchunks / KS;            // k-steps this group walks (KS = 2: chunk = grp + 2 * step)
+
+  // ---- per-lane DMA sources: gather piece e of this wave = piece (gw + GW * e) of the image: lane -> tile pixel piece * 16 + lane / 4
+  const char* gsrc[NGP];
+#pragma unroll
+  for (int e = 0; e < NGP; ++e) {
+    const int item = ((gw + GW * e) << 6) + lane;
+    const int px = item >> 2, ps = item & 3;
+    const int cg = ps ^ (((px >> 2) & 1) << 1);
+    const int m = min(m0 + px, p.M - 1);
+    const int n = frmap_div(m, p.dHoWo), rem = m - n * p.HoWo, oy = frmap_div(rem, p.dWo), ox = rem - oy * p.Wp;   // (Wp holds Wo here)
+    gsrc[e] = (px < CAP && m0 + px < mend)
+                  ? (const char*)p.in + ((((size_t)n * p.Hi + (size_t)(oy * p.ds_stride)) * p.Wi + (size_t)(ox * p.ds_stride)) * p.Cin + cg * 8) * sizeof(elem)
+                  : (const char*)g_pp_zero + cg * 16;
+  }
+  const int wblk = NWI == 2 ? (gw >> 1) : (gw >> 2);
+  const int wpart = NWI == 2 ? ((gw & 1) << 1) : (gw & 3);
+  const char* wsrc = (const char*)p.wpk + ((size_t)(nt * (BN / 64) + wblk) * p.nchunks) * 4096 + wpart * 1024 + lane * 16;
+  const unsigned wdst = lds0 + gbase + 3 * IMGB + wblk * 4096 + wpart * 1024;   // + slot * WB
+  const unsigned gdst = lds0 + gbase + gw * 1024;                              // + buffer * IMGB + e * GW * 1024
+
+  auto chunk_of = [&](int st) { return KS == 2 ? grp + 2 * st : st; };
+  auto issue_step = [&](int st) {   // image and slab of this group's k-step st (past the end: valid dummies into buffers nobody reads)
+    const int sc = st < nst ? st : nst - 1;
+    const size_t coff = (size_t)chunk_of(sc) * 64;
+#pragma unroll
+    for (int e = 0; e < NGP; ++e)
+      pp_dma16(st < nst ? gsrc[e] + coff : (const char*)g_pp_zero, gdst + (unsigned)(st % 3) * IMGB + e * (GW * 1024));
+    const char* sp = wsrc + (size_t)chunk_of(sc) * 4096;
+    const unsigned dp = wdst + (unsigned)(st & (RING - 1)) * WB;
+    pp_dma16(sp, dp);
+    if (NWI == 2) pp_dma16(sp + 1024, dp + 1024);
+  };
+  issue_step(0);
+  issue_step(1);
+
+  int Ag[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int at = ((((mslice * MI + mi) << 4) + lr) << 6) | (g << 4);
+    Ag[mi] = at ^ ((at >> 3) & 32);
+  }
+  const int woff = (lr << 6) + ((g ^ (((lr >> 2) & 1) << 1)) << 4);
+  const char* imgs = smem + gbase;
+  const char* slabs = smem + gbase + 3 * IMGB + wn * 4096 + woff;
+
+  f32x4_t acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  pp_wait_vm<0>();
+  pp_barrier();
+  if (grp == 1) pp_barrier();  // group B runs one barrier behind group A from here on
+
+  for (int st = 0; st < nst; ++st) {
+    vec8 wf[NI], pf[MI];
+    {
+      const char* sl = slabs + (st & (RING - 1)) * WB;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wf[ni] = *(const vec8*)(sl + ni * 1024);
+      const char* gb = imgs + (st % 3) * IMGB;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) pf[mi] = *(const vec8*)(gb + Ag[mi]);
+    }
+    issue_step(st + 2);
+    pp_wait_vm<NWI + NGP>();   // everything older than this phase's DMA has landed (step st + 1)
+    pp_wait_lgkm0();           // retired before the barrier: the next phase's DMA re-targets the image buffer of step st - 1 ... st + 2
+    pp_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = TT::mfma(wf[ni], pf[mi], acc[mi][ni]);
+    pp_barrier();
+  }
+  if (grp == 0) pp_barrier();  // balance group B's extra start barrier
+  pp_wait_vm<0>();             // the dummy DMA of the last two phases must not land in the buffers reused below
+  pp_barrier();
+
+  if (KS == 2) {
+    char* xch = smem + (size_t)q * (MI * NI * 1024) + lane * 16;
+    if (grp == 1) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) *(f32x4_t*)(xch + (mi * NI + ni) * 1024) = acc[mi][ni];
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const f32x4_t o = *(const f32x4_t*)(xch + (mi * NI + ni) * 1024);
+          acc[mi][ni][0] += o[0]; acc[mi][ni][1] += o[1]; acc[mi][ni][2] += o[2]; acc[mi][ni][3] += o[3];
+        }
+    }
+    __syncthreads();
+    if (grp == 1) return;
+  }
+  conv_epilogue<TT, MI, NI>(acc, smem + (KS == 2 ? q : wave) * (16 * (NI * 64 + 16)), m0 + mslice * (MI * 16), mend, p.Cout,
+                            nt * BN + wn * 64, p.shift, (const elem*)p.res, (elem*)p.out, p.relu, lane);
+}
+
+// ================================================================================================
 // 3x3 STRIDE-2 convolutions (ResNet layer{2,3,4}.0.conv1) on the same pipeline, by space-to-depth ADDRESSING.
 //
 // out(oy, ox) reads in(2oy + kh - 1, 2ox + kw - 1).  Write 2oy + kh - 1 = 2(oy + a) + dy: kh = 0 -> (a, dy) = (-1, 1),
@@ -927,6 +1071,94 @@ int frmap_conv3x3_pp_pool(const void* in, const void* w_packed, const float* shi
   rc = dtype == FRMAP_BF16 ? PPP_GO(BF16) : PPP_GO(F16);
 #undef PPP_GO
   return rc ? rc : 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1x1 conv / Linear launcher (conv1x1_pp_kernel): 1 = launched, 0 = shape not taken, < 0 = error; in == nullptr: plan only
+// (returns the layout: 1 = 224 px x 256 ch, 2 = 448 px x 128 ch, 3 = 224 px x 128 ch split-K)
+// ------------------------------------------------------------------------------------------------
+template <typename TT, int WM, int KS>
+static int pp1_launch(const PPParams& p, hipStream_t st) {
+  constexpr int MI = 7;
+  auto kern = conv1x1_pp_kernel<TT, MI, WM, KS>;
+  if (frmap_big_lds((const void*)kern, 160 * 1024)) return -2;
+  constexpr int CAP = (KS == 2 ? 2 : WM) * MI * 16, GW = 8 / KS, NGP = (CAP / 16 + GW - 1) / GW;
+  const int wb = (KS == 2 ? 2 : 8 / WM) * 64 * 64;
+  int lds = KS * (3 * NGP * GW * 1024 + 4 * wb);
+  const int scratch = 8 * 16 * (4 * 64 + 16);
+  const int xch = KS == 2 ? 4 * MI * 4 * 1024 : 0;
+  if (lds < scratch) lds = scratch;
+  if (lds < xch) lds = xch;
+  hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles), dim3(512), lds, st, p);
+  FRMAP_LAUNCH_CHECK();
+  return 0;
+}
+
+int frmap_conv1x1_pp(const void* in, const void* w_packed, const float* shift, const void* residual, void* out, int B, int Hi,
+                     int Wi, int Cin, int Cout, int stride, int relu, int dtype, hipStream_t st) {
+  static int on = -1, min_tiles = 200;
+  if (on < 0) {
+    on = pp_env("FRMAP_CONV_PP", 1) && pp_env("FRMAP_CONV_PP_1X1", 1);
+    min_tiles = pp_env("FRMAP_PP_MIN_TILES", 200);
+  }
+  if (g_pp_on >= 0 ? !g_pp_on : !on) return 0;
+  if (Cin % 32 || Cin > 16384 || Cout % 128 || stride < 1) return 0;
+  const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
+  const long long Mll = (long long)B * Ho * Wo;
+  if (Mll >= (1ll << 31) || (long long)B * Hi * Wi * Cin * 2 >= (1ll << 46)) return 0;
+  PPParams p;
+  p.in = in; p.wpk = w_packed; p.shift = shift; p.res = residual; p.out = out;
+  p.N = B; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
+  p.M = (int)Mll; p.HoWo = Ho * Wo; p.Hp = Ho; p.Wp = Wo;          // (output geometry: the kernel needs no padded map)
+  p.magic_Wp = frmap_magic((uint32_t)p.Wp); p.magic_Hp = frmap_magic((uint32_t)p.Hp);
+  p.dHoWo = frmap_div_make((uint32_t)p.HoWo); p.dWo = frmap_div_make((uint32_t)Wo);
+  p.nchunks = Cin / 32;
+  p.ds_in = nullptr; p.ds_w = nullptr; p.ds_Hi = p.ds_Wi = p.ds_Cin = p.dsc = 0; p.ds_stride = stride;
+  p.Wo2 = 0; p.dWo2 = frmap_div_make(1u);
+  // layouts: 1 = 224 px x 256 ch, 2 = 448 px x 128 ch, 3 = split-K 224 px x 128 ch.  One workgroup per CU, so what counts is
+  // ROUNDS x time per tile: est = ceil(tiles / CUs) x (k-steps per group x 0.6 us + 7.5 us of prologue and epilogue); 280 tiles
+  // on 256 CUs are two rounds.  The first-generation kernel (small tiles, two workgroups per CU) is modelled at 470 TFLOP/s.
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0, v = 0;
+    ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  auto est_us = [&](int lay) -> double {
+    if (lay == 1 && Cout % 256) return 1e30;
+    if (lay == 3 && p.nchunks % 2) return 1e30;
+    const int px = lay == 2 ? 448 : 224, bn = lay == 1 ? 256 : 128;
+    const long long tiles = ((Mll + px - 1) / px) * (Cout / bn);
+    const long long rounds = (tiles + ncu - 1) / ncu;
+    return (double)rounds * ((lay == 3 ? p.nchunks / 2 : p.nchunks) * 0.6 + 7.5);
+  };
+  int layout = 0;
+  double best = 1e30;
+  for (int lay = 1; lay <= 3; ++lay) {
+    if (g_pp_bn == 256 && g_pp_ks != 2 && lay != 1 && Cout % 256 == 0) continue;   // forced by the tuning hook
+    if (g_pp_bn == 128 && g_pp_ks == 1 && lay != 2) continue;
+    if (g_pp_ks == 2 && lay != 3 && p.nchunks % 2 == 0) continue;
+    const double e = est_us(lay);
+    if (e < best) { best = e; layout = lay; }
+  }
+  if (!layout || best >= 1e30) return 0;
+  if (g_pp_on < 0) {
+    const double gen1_us = 2.0 * (double)Mll * Cin * Cout / 470e6;
+    if (best > gen1_us || min_tiles < 0) return 0;
+  }
+  p.tile_px = layout == 2 ? 448 : 224;
+  p.mtiles = (int)((Mll + p.tile_px - 1) / p.tile_px);
+  p.ntiles = Cout / (layout == 1 ? 256 : 128);
+  if (!in) return layout;
+  int rc;
+#define PP1_GO(TT) (layout == 1 ? pp1_launch<TT, 2, 1>(p, st) : layout == 2 ? pp1_launch<TT, 4, 1>(p, st) : pp1_launch<TT, 2, 2>(p, st))
+  rc = dtype == FRMAP_BF16 ? PP1_GO(BF16) : PP1_GO(F16);
+#undef PP1_GO
+  return rc ? rc : 1;
+}
+
+extern "C" int frmap_conv1x1_pp_layout(int B, int Hi, int Wi, int Cin, int Cout, int stride) {
+  if (B <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  return frmap_conv1x1_pp(nullptr, nullptr, nullptr, nullptr, nullptr, B, Hi, Wi, Cin, Cout, stride, 0, FRMAP_BF16, nullptr);
 }
 
 extern "C" int frmap_conv3x3_pp_pool_layout(int B, int Hi, int Wi, int Cin, int Cout) {

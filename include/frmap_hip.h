@@ -152,6 +152,10 @@ int frmap_conv_igemm_pool2_supported(int B, int Hi, int Wi, int Cin, int Cout);
  * slice: Wi in {2,4,8,14,28,56}, Cin >= 128, Cout % 128 == 0), 2 = weights-resident wave kernel (Cin 32 / 64, Hi and Wi
  * multiples of 8), 1 = generic kernel, 0 = not taken.  frmap_conv3x3_pp_pool_layout: 1 when the ping-pong form fits. */
 int frmap_conv_igemm_pool2_form(int B, int Hi, int Wi, int Cin, int Cout);
+/* does a 1x1 conv / Linear layer (stride s, pad 0; Linear: Hi = Wi = 1, B = rows) take the LDS-DMA ping-pong kernel
+ * (conv1x1_pp_kernel)?  1 = 224 px x 256 ch tiles, 2 = 448 px x 128 ch, 3 = 224 px x 128 ch with split-K, 0 = the
+ * first-generation 1x1 kernel runs it (Cin % 32, Cout % 128, too few tiles). */
+int frmap_conv1x1_pp_layout(int B, int Hi, int Wi, int Cin, int Cout, int stride);
 int frmap_conv3x3_pp_pool_layout(int B, int Hi, int Wi, int Cin, int Cout);
 int frmap_conv_igemm_pool2(const void* in, const void* w_packed, const float* shift, void* out, int B, int Hi,
                            int Wi, int Cin, int Cout, int relu, int dtype, void* stream);

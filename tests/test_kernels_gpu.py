@@ -647,3 +647,45 @@ def test_match_top1_mfma_path_equals_fp32_path():
     g[0, 0] += 1.0     # in-place edit: the pack is stale and must be refused
     with pytest.raises(ValueError):
         ops.match_top1(synth.unit_rows(2, 4, 512, "e").to(DEV), g, 1.0, prepared=prep)
+
+
+def test_conv1x1_pp_kernel():
+    """`conv1x1_pp_kernel` (1x1 convs / wide Linear layers on the LDS-DMA ping-pong pipeline) against fp32 torch and the
+    first-generation 1x1 kernel: the three layouts (224 px x 256 ch, 448 px x 128 ch, split-K), stride 1 and 2, Linear shapes
+    (H = W = 1: HybridNet's QKV / out-projection / MLP over 49 tokens x faces), residual + ReLU / GELU, ragged tails, a
+    single k-step, odd k-step counts."""
+    from frmap_amd import _lib
+    lib = _lib.load()
+    cases = [  # B, H, W, Cin, Cout, stride, residual, act, bn (-1 heuristic, 128, 256, 1282 split-K)
+        (3, 14, 14, 256, 256, 1, False, 1, 256), (5, 14, 14, 256, 512, 1, True, 1, 128), (2, 28, 28, 128, 256, 2, False, 0, -1),
+        (2, 56, 56, 64, 128, 2, False, 1, 128), (637, 1, 1, 512, 1536, 1, False, 0, 256), (637, 1, 1, 2048, 512, 1, True, 0, 1282),
+        (1001, 1, 1, 512, 2048, 1, False, 2, 128), (9, 7, 7, 1024, 384, 1, True, 2, -1), (300, 1, 1, 32, 128, 1, False, 1, 256),
+        (450, 1, 1, 96, 256, 1, True, 1, 1282), (4, 13, 9, 160, 640, 1, False, 1, 1282), (1, 1, 1, 512, 512, 1, False, 0, 256),
+    ]
+    try:
+        for ci, (B, H, W, Cin, Cout, sd, res, act, bn) in enumerate(cases):
+            for dtype in DTYPES:
+                x = synth.randn(9500 + ci, (B, Cin, H, W), "x").to(dtype)
+                w = (synth.randn(9510 + ci, (Cout, Cin, 1, 1), "w") * math.sqrt(1.0 / Cin)).to(dtype)
+                shift = synth.randn(9520 + ci, (Cout,), "b") * 0.1
+                ref = F.conv2d(x.float(), w.float(), None, stride=sd) + shift.view(1, -1, 1, 1)
+                r = synth.randn(9530 + ci, tuple(ref.shape), "r").to(dtype) if res else None
+                if res:
+                    ref = ref + r.float()
+                ref = F.relu(ref) if act == 1 else (F.gelu(ref) if act == 2 else ref)
+                wpk = ops.pack_conv_weight(w.float().to(DEV), dtype)
+                xin, rin = _nhwc(x).to(DEV), (_nhwc(r).to(DEV) if res else None)
+                lib.frmap_conv_pp_tuning(1, -1, bn)
+                want = {256: 1 if Cout % 256 == 0 else 2, 128: 2, 1282: 3 if (Cin // 32) % 2 == 0 else None}.get(bn)
+                lay = lib.frmap_conv1x1_pp_layout(B, H, W, Cin, Cout, sd)
+                assert lay in (1, 2, 3) and (want is None or lay == want), (ci, lay, want)
+                y_pp = ops.conv_igemm(xin, wpk, shift.to(DEV), Cout, 1, sd, 0, act, rin)
+                lib.frmap_conv_pp_tuning(0, -1, -1)
+                y_g1 = ops.conv_igemm(xin, wpk, shift.to(DEV), Cout, 1, sd, 0, act, rin)
+                atol, rtol = _tol(dtype)
+                y = y_pp.float().cpu().permute(0, 3, 1, 2)
+                assert y.shape == ref.shape
+                assert torch.allclose(y, ref, atol=atol, rtol=rtol), (ci, dtype, float((y - ref).abs().max()))
+                assert torch.allclose(y_pp.float(), y_g1.float(), atol=atol, rtol=rtol), (ci, dtype, "generations differ")
+    finally:
+        lib.frmap_conv_pp_tuning(-1, -1, -1)
