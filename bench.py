@@ -227,7 +227,7 @@ def instrument(ops, torch, dt):
     def d_match(out, emb, gallery, thresh=None, packed=False, prepared=None):
         G = 0 if gallery is None else gallery.shape[0]
         if prepared is not None and G >= ops.MATCH_MFMA_MIN_G:   # fp16 (hi, lo) split: 3 MFMA products per fp32 one
-            return ("match_top1 (conv1x1_kernel<F16, MATCH> + finalize)", 6.0 * emb.shape[0] * emb.shape[1] * G,
+            return ("match_top1 (conv1x1_pp_kernel<F16, MATCH> + finalize)", 6.0 * emb.shape[0] * emb.shape[1] * G,
                     _nbytes(emb) + _nbytes(prepared.packed) + 16 * emb.shape[0])
         return "match_top1 (gemm_nt_f32_kernel + finalize)", 2.0 * emb.shape[0] * emb.shape[1] * G, _nbytes(emb) + _nbytes(gallery) + 16 * emb.shape[0]
 

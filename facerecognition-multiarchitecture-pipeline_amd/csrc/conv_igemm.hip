@@ -1494,8 +1494,13 @@ extern "C" int frmap_conv_igemm_pool2(const void* in, const void* w_packed, cons
 // ------------------------------------------------------------------------------------------------
 int frmap_match_gemm_f16x3(const void* probes3, const void* gallery_packed, const float* stat_a, const float* stat_w,
                            unsigned long long* keys, int B, int G, int D, hipStream_t st) {
-  const int K3 = 3 * D, Gpad = (G + 63) / 64 * 64;
+  const int K3 = 3 * D, Gpad = (G + 255) / 256 * 256;   // (the packed gallery is padded to 256 rows: frmap_match_gallery_pack_bytes)
   FRMAP_REQUIRE(K3 % 32 == 0, "match: D=%d must be a multiple of 32", D);
+  {
+    const int rc = frmap_match_gemm_pp(probes3, gallery_packed, stat_a, stat_w, keys, B, G, Gpad, D, st);
+    if (rc < 0) return rc;
+    if (rc == 1) return 0;
+  }
   ConvParams p;
   memset(&p, 0, sizeof(p));
   p.in = probes3; p.wpk = gallery_packed;

@@ -27,6 +27,7 @@
 //   problem are fetched from valid dummy addresses into buffers nobody reads).
 #include "frmap_common.h"
 #include <stdlib.h>
+#include <string.h>
 
 #include <array>
 #include <map>
@@ -53,6 +54,11 @@ struct PPParams {
   // fused MaxPool2d(2, 2) (PL = true): each wave's 112-pixel slice (whole row pairs) is walked in pool-major order
   int Wo2;         // Wi / 2
   FrmapDiv dWo2;
+  // conv1x1_pp_kernel<..., MATCH = true> (top-1 gallery match, head_match.hip): per-row statistics and the arg-min keys
+  const float* m_stat_a;        // [M][4] = (sum a^2, sum a, 1 / row scale, row scale) of the fp32 probes
+  const float* m_stat_w;        // [G][4] of the fp32 gallery rows
+  unsigned long long* m_keys;   // [M] packed (bits(d^2) << 32 | row), atomicMin
+  int m_G, m_D;
 };
 
 __device__ __attribute__((aligned(4096))) unsigned int g_pp_zero[1024];
@@ -500,7 +506,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
 // KS = 2: 224 px x 128 ch with the two wave groups splitting K (own buffers; accumulators merged through LDS) for outputs with
 // few tiles (Linear 2048 -> 512 over 12 544 tokens: 224 tiles instead of 112).
 // ================================================================================================
-template <typename TT, int MI, int WM, int KS>
+// MATCH = true: the epilogue of conv1x1_kernel<..., MATCH> (conv_igemm.hip): the GEMM is probes x gallery rows in split fp16
+// operands, each lane forms the expanded squared F.pairwise_distance of its 16 gallery rows, the column's four lanes meet
+// through two shuffles, one 64-bit atomicMin per probe and tile.
+template <typename TT, int MI, int WM, int KS, bool MATCH = false>
 __global__ __launch_bounds__(512, 2) void conv1x1_pp_kernel(const PPParams p) {
   constexpr int NI = 4, WN = KS == 2 ? 2 : 8 / WM;
   constexpr int CAP = (KS == 2 ? 2 : WM) * MI * 16;          // pixels of a tile
@@ -628,6 +637,42 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pp_kernel(const PPParams p) {
     }
     __syncthreads();
     if (grp == 1) return;
+  }
+  if constexpr (MATCH) {
+    const int n0 = nt * BN + wn * 64;
+    float w2[NI][4], ws[NI][4], wi[NI][4];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = min(n0 + ni * 16 + 4 * g + j, p.m_G - 1);
+        const f32x4_t sw = *(const f32x4_t*)(p.m_stat_w + 4 * (size_t)n);
+        w2[ni][j] = sw[0]; ws[ni][j] = sw[1]; wi[ni][j] = sw[2];
+      }
+    const float eps = 1e-6f, keps = (float)p.m_D * eps * eps;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int b = m0 + mslice * (MI * 16) + mi * 16 + lr;
+      const f32x4_t sa = *(const f32x4_t*)(p.m_stat_a + 4 * (size_t)min(b, p.M - 1));
+      const float a2 = sa[0], as = sa[1], ai = sa[2];
+      unsigned long long key = ~0ull;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = n0 + ni * 16 + 4 * g + j;
+          float d2 = a2 + w2[ni][j] - 2.f * (acc[mi][ni][j] * ai * wi[ni][j]) + 2.f * eps * (as - ws[ni][j]) + keps;
+          d2 = fmaxf(d2, 0.f);
+          const unsigned long long k2 = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)n;
+          if (n < p.m_G && k2 < key) key = k2;
+        }
+      unsigned long long o = __shfl_xor(key, 16, 64);
+      key = o < key ? o : key;
+      o = __shfl_xor(key, 32, 64);
+      key = o < key ? o : key;
+      if (g == 0 && b < mend && key != ~0ull) atomicMin(p.m_keys + b, key);
+    }
+    return;
   }
   conv_epilogue<TT, MI, NI>(acc, smem + (KS == 2 ? q : wave) * (16 * (NI * 64 + 16)), m0 + mslice * (MI * 16), mend, p.Cout,
                             nt * BN + wn * 64, p.shift, (const elem*)p.res, (elem*)p.out, p.relu, lane);
@@ -1077,10 +1122,10 @@ int frmap_conv3x3_pp_pool(const void* in, const void* w_packed, const float* shi
 // 1x1 conv / Linear launcher (conv1x1_pp_kernel): 1 = launched, 0 = shape not taken, < 0 = error; in == nullptr: plan only
 // (returns the layout: 1 = 224 px x 256 ch, 2 = 448 px x 128 ch, 3 = 224 px x 128 ch split-K)
 // ------------------------------------------------------------------------------------------------
-template <typename TT, int WM, int KS>
+template <typename TT, int WM, int KS, bool MATCH = false>
 static int pp1_launch(const PPParams& p, hipStream_t st) {
   constexpr int MI = 7;
-  auto kern = conv1x1_pp_kernel<TT, MI, WM, KS>;
+  auto kern = conv1x1_pp_kernel<TT, MI, WM, KS, MATCH>;
   if (frmap_big_lds((const void*)kern, 160 * 1024)) return -2;
   constexpr int CAP = (KS == 2 ? 2 : WM) * MI * 16, GW = 8 / KS, NGP = (CAP / 16 + GW - 1) / GW;
   const int wb = (KS == 2 ? 2 : 8 / WM) * 64 * 64;
@@ -1153,6 +1198,34 @@ int frmap_conv1x1_pp(const void* in, const void* w_packed, const float* shift, c
 #define PP1_GO(TT) (layout == 1 ? pp1_launch<TT, 2, 1>(p, st) : layout == 2 ? pp1_launch<TT, 4, 1>(p, st) : pp1_launch<TT, 2, 2>(p, st))
   rc = dtype == FRMAP_BF16 ? PP1_GO(BF16) : PP1_GO(F16);
 #undef PP1_GO
+  return rc ? rc : 1;
+}
+
+// top-1 match GEMM on the same kernel (see frmap_match_gemm_f16x3 in conv_igemm.hip): G padded to 256 rows, K3 = 3 D.
+// 1 = launched, 0 = not taken
+int frmap_match_gemm_pp(const void* probes3, const void* gallery_packed, const float* stat_a, const float* stat_w,
+                        unsigned long long* keys, int B, int G, int Gpad, int D, hipStream_t st) {
+  static int on = -1;
+  if (on < 0) on = pp_env("FRMAP_CONV_PP", 1) && pp_env("FRMAP_MATCH_PP", 1);
+  const int K3 = 3 * D;
+  if (!on || Gpad % 256 || K3 % 32 || K3 > 16384 || B <= 0) return 0;
+  PPParams p;
+  memset(&p, 0, sizeof(p));
+  p.in = probes3; p.wpk = gallery_packed;
+  p.N = B; p.Hi = 1; p.Wi = 1; p.Cin = K3; p.Cout = Gpad;
+  p.M = B; p.HoWo = 1; p.Hp = 1; p.Wp = 1;
+  p.magic_Wp = frmap_magic(1u); p.magic_Hp = frmap_magic(1u);
+  p.dHoWo = frmap_div_make(1u); p.dWo = frmap_div_make(1u); p.dWo2 = frmap_div_make(1u);
+  p.nchunks = K3 / 32; p.ds_stride = 1;
+  p.m_stat_a = stat_a; p.m_stat_w = stat_w; p.m_keys = keys; p.m_G = G; p.m_D = D;
+  // 224 probes x 256 gallery rows per tile, or 448 x 128 when that fills the CUs better (one round either way at 1024 probes)
+  const long long t1 = ((B + 223) / 224) * (long long)(Gpad / 256), t2 = ((B + 447) / 448) * (long long)(Gpad / 128);
+  const long long r1 = (t1 + 255) / 256, r2 = (t2 + 255) / 256;   // rounds on 256 CUs (a tile costs the same in both layouts)
+  const bool wide = r2 < r1 || (r2 == r1 && t2 > t1);             // same rounds: the layout that occupies more CUs
+  p.tile_px = wide ? 448 : 224;
+  p.mtiles = (B + p.tile_px - 1) / p.tile_px;
+  p.ntiles = Gpad / (wide ? 128 : 256);
+  const int rc = wide ? pp1_launch<F16, 4, 1, true>(p, st) : pp1_launch<F16, 2, 1, true>(p, st);
   return rc ? rc : 1;
 }
 

@@ -280,6 +280,8 @@ int frmap_conv3x3_pp_pool(const void* in, const void* w_packed, const float* shi
 // 1x1 conv / Linear on the LDS-DMA ping-pong pipeline (conv1x1_pp_kernel): 1 = launched, 0 = not taken, < 0 = error
 int frmap_conv1x1_pp(const void* in, const void* w_packed, const float* shift, const void* residual, void* out, int B, int Hi,
                      int Wi, int Cin, int Cout, int stride, int relu, int dtype, hipStream_t st);
+int frmap_match_gemm_pp(const void* probes3, const void* gallery_packed, const float* stat_a, const float* stat_w,
+                        unsigned long long* keys, int B, int G, int Gpad, int D, hipStream_t st);
 // top-1 match GEMM on the 1x1 MFMA kernel (conv_igemm.hip), see frmap_match_top1_packed
 int frmap_match_gemm_f16x3(const void* probes3, const void* gallery_packed, const float* stat_a, const float* stat_w,
                            unsigned long long* keys, int B, int G, int D, hipStream_t st);

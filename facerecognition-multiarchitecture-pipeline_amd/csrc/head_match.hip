@@ -859,7 +859,7 @@ __global__ void match_pack_gallery_kernel(const float* __restrict__ gal, const f
 
 extern "C" size_t frmap_match_gallery_pack_bytes(int G, int D) {
   if (G <= 0 || D <= 0) return 0;
-  return (size_t)((G + 63) / 64 * 64) * 3 * D * sizeof(_Float16);
+  return (size_t)((G + 255) / 256 * 256) * 3 * D * sizeof(_Float16);
 }
 
 // one-time preparation of a gallery for frmap_match_top1_packed: packed_out (frmap_match_gallery_pack_bytes), stat_w_out [G][4]
@@ -868,7 +868,7 @@ extern "C" int frmap_match_pack_gallery(const float* gallery, void* packed_out, 
   FRMAP_REQUIRE(G > 0 && D > 0 && D % 32 == 0, "match_pack_gallery: bad shape G=%d D=%d (D %% 32 == 0)", G, D);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(match_row_prep_kernel, dim3(waves_blocks(G)), dim3(256), 0, st, gallery, stat_w_out, (_Float16*)nullptr, G, D);
-  const size_t total = (size_t)((G + 63) / 64 * 64) * 3 * D;
+  const size_t total = (size_t)((G + 255) / 256 * 256) * 3 * D;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(match_pack_gallery_kernel, dim3(blocks), dim3(256), 0, st, gallery, (const float*)stat_w_out,
                      (_Float16*)packed_out, total, G, D);
