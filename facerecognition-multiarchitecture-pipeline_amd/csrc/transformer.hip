@@ -23,6 +23,57 @@ __global__ void add_pos_layernorm_kernel(const typename TT::elem* __restrict__ x
   const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (row >= rows) return;
   const int l = row % L;
+  if (D % 512 == 0) {   // 16-byte path: lane owns channels 8 * lane .. + 7 of every 512-channel block
+    float v[2][8];
+    float s = 0.f;
+    const int nb = D >> 9;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (i >= nb) break;
+      const int d = i * 512 + lane * 8;
+      float f[8];
+      unpack8<TT>(*(const u32x4_t*)(x + (size_t)row * D + d), f);
+      if (pos) {
+        const f32x4_t p0 = *(const f32x4_t*)(pos + (size_t)l * D + d), p1 = *(const f32x4_t*)(pos + (size_t)l * D + d + 4);
+        f[0] += p0[0]; f[1] += p0[1]; f[2] += p0[2]; f[3] += p0[3]; f[4] += p1[0]; f[5] += p1[1]; f[6] += p1[2]; f[7] += p1[3];
+      }
+      if (t_out) {
+        const u32x4_t r = pack8<TT>(f);
+        *(u32x4_t*)(t_out + (size_t)row * D + d) = r;
+        unpack8<TT>(r, f);   // the residual stream is stored in `dtype`; normalise what was stored
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { v[i][j] = f[j]; s += f[j]; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (i >= nb) break;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float c = v[i][j] - mean; q += c * c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = rsqrtf(q / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (i >= nb) break;
+      const int d = i * 512 + lane * 8;
+      const f32x4_t g0 = *(const f32x4_t*)(gamma + d), g1 = *(const f32x4_t*)(gamma + d + 4);
+      const f32x4_t b0 = *(const f32x4_t*)(beta + d), b1 = *(const f32x4_t*)(beta + d + 4);
+      float y[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        y[j] = (v[i][j] - mean) * rstd * g0[j] + b0[j];
+        y[4 + j] = (v[i][4 + j] - mean) * rstd * g1[j] + b1[j];
+      }
+      *(u32x4_t*)(y_out + (size_t)row * D + d) = pack8<TT>(y);
+    }
+    return;
+  }
   const int per = D >> 6;  // elements per lane (<= 16), strided by 64 so loads stay coalesced
   float v[16];
   float s = 0.f;
@@ -224,14 +275,48 @@ __global__ __launch_bounds__(256) void mean_layernorm_kernel(const typename TT::
                                                              const float* __restrict__ beta, float* __restrict__ out,
                                                              int L, int D, float eps) {
   __shared__ float red[8];
+  __shared__ float part_sum[4][1024];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (D + 255) / 256;  // <= 4
   float m[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int l = 0; l < L; ++l) {
+  if (D % 8 == 0 && D <= 1024) {
+    // 16-byte loads: 8-channel group c8 x token subset `sub` per thread (D / 8 groups x as many subsets as fit in 256 threads),
+    // up to 7 independent loads in flight per thread; the subsets meet in LDS
+    const int C8 = D >> 3, nsub = C8 <= 256 ? min(4, 256 / C8) : 1;
+    if (tid < C8 * nsub) {
+      const int c8 = tid % C8, sub = tid / C8;
+      float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      const typename TT::elem* src = t + (size_t)b * L * D + c8 * 8;
+      for (int l0 = sub; l0 < L; l0 += 7 * nsub) {
+        u32x4_t r[7];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) r[u] = *(const u32x4_t*)(src + (size_t)min(l0 + u * nsub, L - 1) * D);
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+          float v[8];
+          unpack8<TT>(r[u], v);
+          const float w = l0 + u * nsub < L ? 1.0f : 0.0f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a[j] = fmaf(w, v[j], a[j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) part_sum[sub][c8 * 8 + j] = a[j];
+    }
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int d = i * 256 + tid;
-      if (i < per && d < D) m[i] += TT::to_f32(t[((size_t)b * L + l) * D + d]);
+      if (i < per && d < D)
+        for (int sub = 0; sub < nsub; ++sub) m[i] += part_sum[sub][d];
+    }
+  } else {
+    for (int l = 0; l < L; ++l) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int d = i * 256 + tid;
+        if (i < per && d < D) m[i] += TT::to_f32(t[((size_t)b * L + l) * D + d]);
+      }
     }
   }
   float s = 0.f;
