@@ -440,21 +440,33 @@ __global__ __launch_bounds__(256) void gap_norm_match_kernel(const typename TT::
   // compare_faces scan (as match_small_kernel): wave w scores rows 8w..8w+7, 8(w+4)..; first strict minimum wins
   float best = INFINITY;
   int besti = 0x7FFFFFFF;
-  for (int g0 = 0; g0 < G; g0 += 64) {  // this pass: rows g0 + wave, g0 + wave + 4, ... (16 per wave: one pass for G <= 64)
-    float s2[16];
+  constexpr int RPW = 10;   // gallery rows per wave and pass: 40 rows per pass (the 36-ID gallery in one)
+  for (int g0 = 0; g0 < G; g0 += 4 * RPW) {  // this pass: rows g0 + wave, g0 + wave + 4, ...
+    // lane l owns dims 8 l .. 8 l + 7 of every 512-dim block: all of a pass's gallery reads (10 rows x 2 x 16 bytes per block)
+    // are issued before the first use - one L2 round trip per pass instead of one per 64 dims
+    float s2[RPW];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) s2[j] = 0.f;
-    for (int k = lane; k < C; k += 64) {
-      const float e = s_e[k];
+    for (int j = 0; j < RPW; ++j) s2[j] = 0.f;
+    for (int kk = lane * 8; kk < C; kk += 512) {
+      f32x4_t r[RPW][2];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int gi = min(g0 + 4 * j + wave, G - 1);
-        const float d = (e - gal[(size_t)gi * C + k]) + 1e-6f;
-        s2[j] += d * d;
+      for (int j = 0; j < RPW; ++j) {
+        const float* gp = gal + (size_t)min(g0 + 4 * j + wave, G - 1) * C + kk;
+        r[j][0] = *(const f32x4_t*)gp;
+        r[j][1] = *(const f32x4_t*)(gp + 4);
       }
+      const f32x4_t e0 = *(const f32x4_t*)(s_e + kk), e1 = *(const f32x4_t*)(s_e + kk + 4);
+#pragma unroll
+      for (int j = 0; j < RPW; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float d0 = (e0[c] - r[j][0][c]) + 1e-6f, d1 = (e1[c] - r[j][1][c]) + 1e-6f;
+          s2[j] = fmaf(d0, d0, s2[j]);
+          s2[j] = fmaf(d1, d1, s2[j]);
+        }
     }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {  // ascending row index within the wave: strict < keeps the first minimum
+    for (int j = 0; j < RPW; ++j) {  // ascending row index within the wave: strict < keeps the first minimum
       float v = s2[j];
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
