@@ -152,6 +152,9 @@ def _conv_kernel_name(dt, Cin, k, stride, H, W, ds, Cout=0, B=0):
     if ds:
         return f"conv3x3_fast_kernel<{dt}, true>"
     if k == 1:
+        from frmap_amd import _lib
+        if Cin >= 128 and _lib.load().frmap_conv1x1_pp_layout(B, H, W, Cin, Cout, stride):
+            return f"conv1x1_pp_kernel<{dt}>"
         return f"conv1x1_kernel<{dt}>"
     if stride == 2:
         return f"conv3x3s2_fast_kernel<{dt}>"
@@ -230,6 +233,44 @@ def instrument(ops, torch, dt):
             return ("match_top1 (conv1x1_pp_kernel<F16, MATCH> + finalize)", 6.0 * emb.shape[0] * emb.shape[1] * G,
                     _nbytes(emb) + _nbytes(prepared.packed) + 16 * emb.shape[0])
         return "match_top1 (gemm_nt_f32_kernel + finalize)", 2.0 * emb.shape[0] * emb.shape[1] * G, _nbytes(emb) + _nbytes(gallery) + 16 * emb.shape[0]
+
+    # the other model families' ops (bench.py --model baseline / siamese / hybrid / attention): generic descriptions - the
+    # algorithmic bytes are the operand and result tensors, the FLOPs those of the contraction (0 for pure data movement)
+    def _tensors(*xs):
+        return sum(_nbytes(x) for x in xs if isinstance(x, torch.Tensor))
+
+    def d_pool2(out, x, wpk, shift, Cout, relu):
+        B, H, W, Cin = x.shape
+        form = {3: "conv3x3_pp_kernel<PL>", 2: "conv3x3_c64_wave_kernel<POOL>", 1: "conv_igemm_kernel<POOL>"}.get(ops.conv_pool2_form(B, H, W, Cin, Cout), "conv+pool")
+        return f"{form}<{dt}> (conv3x3 + 2x2 max-pool)", 2.0 * B * H * W * Cout * Cin * 9, _tensors(x, wpk, out)
+
+    def d_c3pool(out, x4, wpk, shift, Cout, relu):
+        B, H, W, _ = x4.shape
+        return f"conv_small_cin_kernel<{dt}, POOL>", 2.0 * B * H * W * Cout * 27, _tensors(x4, wpk, out)
+
+    def d_c3(out, x4, wpk, shift, Cout, k, stride, pad, relu):
+        return f"conv_small_cin_kernel<{dt}>", 2.0 * out.shape[0] * out.shape[1] * out.shape[2] * Cout * 3 * k * k, _tensors(x4, wpk, out)
+
+    def d_linmfma(out, x2d, wpk, shift, N, act=0, residual=None):
+        return f"linear_mfma<{dt}> (1x1 MFMA kernels)", 2.0 * x2d.shape[0] * x2d.shape[1] * N, _tensors(x2d, wpk, out, residual)
+
+    def d_move(label):
+        def f(out, *a, **kw):
+            outs = out if isinstance(out, (tuple, list)) else (out,)
+            return label, 0.0, _tensors(*a) + _tensors(*outs)
+        return f
+
+    def d_mha(out, qkv, H):
+        B, L, D3 = qkv.shape
+        return f"mha_tokens_kernel<{dt}>", 4.0 * B * L * L * (D3 // 3), _tensors(qkv, out)
+
+    for name, fn in (("conv_igemm_pool2", d_pool2), ("conv_small_cin_pool2", d_c3pool), ("conv_small_cin", d_c3), ("linear_mfma", d_linmfma),
+                     ("maxpool", d_move("maxpool_kernel")), ("avgpool_adaptive", d_move("avgpool_adaptive_kernel")),
+                     ("pack_input", d_move("pack_input_kernel")), ("add_pos_layernorm", d_move("add_pos_layernorm_kernel")),
+                     ("mean_layernorm", d_move("mean_layernorm_kernel")), ("mha_tokens", d_mha),
+                     ("cnn_attention", d_move("cnn_attention_kernel")), ("cast_to_f32", d_move("cast_to_f32_kernel"))):
+        if hasattr(ops, name):
+            wrap(name, fn)
 
     for name, fn in (("conv_igemm", d_conv), ("conv_igemm_ds", d_conv_ds), ("stem7x7_maxpool", d_stem),
                      ("stem7x7_maxpool_u8", d_stem_u8), ("gap_norm_match", d_gnm), ("gap_linear_norm", d_head), ("avgpool_global", d_pool),
