@@ -110,7 +110,7 @@ def test_cabi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.frmap_abi_version() == _lib.ABI_VERSION
-    assert lib.frmap_small_cin_kpad(7, 7) == 232 and lib.frmap_small_cin_kpad(3, 3) == 72
+    assert lib.frmap_small_cin_kpad(7, 7) == 240 and lib.frmap_small_cin_kpad(3, 3) == 80   # K + 16: the bank-conflict-free pitch
     assert lib.frmap_head_workspace_bytes(4, 4) >= 8 * 16
 
 
