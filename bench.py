@@ -214,7 +214,7 @@ def instrument(ops, torch, dt):
         G = 0 if gallery is None else gallery.shape[0]
         return f"gap_norm_match_kernel<{dt}>", 2.0 * B * C * G, _nbytes(fmap) + _nbytes(gallery) + 16 * B
 
-    def d_head(out, fmap, wt, scale, shift, eps=1e-12, want_pre=False):
+    def d_head(out, fmap, wt, scale, shift, eps=1e-12, want_pre=False, relu=False):
         B, H, W, K = fmap.shape
         return f"gap_linear_norm_kernel<{dt}>", 2.0 * B * K * wt.shape[1], _nbytes(fmap) + _nbytes(wt) + _nbytes(out[0])
 

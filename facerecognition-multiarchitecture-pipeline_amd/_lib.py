@@ -33,7 +33,7 @@ PROTOTYPES = {
     "frmap_match_pack_gallery": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "frmap_match_top1_packed": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp]),
     "frmap_resize_bilinear_u8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "frmap_gap_linear_norm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp]),
+    "frmap_gap_linear_norm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i, _vp]),
     "frmap_conv_small_cin_pool2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "frmap_conv_igemm_pool2_supported": (_i, [_i, _i, _i, _i, _i]),
     "frmap_conv_igemm_pool2_form": (_i, [_i, _i, _i, _i, _i]),

@@ -524,7 +524,7 @@ template <typename TT, int FB, int NPT>
 __global__ __launch_bounds__(256) void gap_linear_norm_kernel(const typename TT::elem* __restrict__ map, const float* __restrict__ wt,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               float* __restrict__ pre_out, float* __restrict__ emb_out, float eps,
-                                                              int B, int HW, int K) {
+                                                              int B, int HW, int K, int relu) {
   constexpr int N = NPT * 256;
   extern __shared__ float s_all[];
   float* s_x = s_all;                 // [K][FB]
@@ -534,19 +534,24 @@ __global__ __launch_bounds__(256) void gap_linear_norm_kernel(const typename TT:
   const int C8 = K >> 3;
   const float inv = 1.0f / (float)HW;
   // pooling: wave w takes faces w and w + 4 side by side (two independent accumulator sets: 16 loads of 16 bytes in flight
-  // per lane), lane l the 8-channel groups l, l + 64, ..; every lane walks all HW rows, so no partial sums meet in LDS
+  // per lane).  K >= 512: lane l owns the 8-channel groups l, l + 64, .. and walks all HW rows, nothing meets in LDS.
+  // K < 512 (BaselineNet: 128 channels x 784 pixels): the 64 lanes are K/8 groups x nsub row subsets, whose partial sums
+  // meet in LDS (s_part) in a fixed order.
   static_assert(FB == 8, "two faces per wave, four waves");
+  const int nsub = C8 >= 64 ? 1 : 64 / C8;
+  float* s_part = s_red + FB * 4;   // [FB][nsub][K] (nsub > 1 only)
   {
     const int fa = wave, fb = wave + 4;
     const typename TT::elem* sa = map + (size_t)min(b0 + fa, B - 1) * HW * K;
     const typename TT::elem* sb = map + (size_t)min(b0 + fb, B - 1) * HW * K;
-    for (int c8 = lane; c8 < C8; c8 += 64) {
+    const int sub = nsub > 1 ? lane / C8 : 0;
+    for (int c8 = nsub > 1 ? lane % C8 : lane; c8 < C8 && sub < nsub; c8 += 64) {
       float a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int s0 = 0; s0 < HW; s0 += 8) {
+      for (int s0 = sub; s0 < HW; s0 += 8 * nsub) {
         u32x4_t ra[8], rb[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          const size_t o = (size_t)min(s0 + q, HW - 1) * K + c8 * 8;
+          const size_t o = (size_t)min(s0 + q * nsub, HW - 1) * K + c8 * 8;
           ra[q] = *(const u32x4_t*)(sa + o);
           rb[q] = *(const u32x4_t*)(sb + o);
         }
@@ -555,19 +560,37 @@ __global__ __launch_bounds__(256) void gap_linear_norm_kernel(const typename TT:
           float va[8], vb[8];
           unpack8<TT>(ra[q], va);
           unpack8<TT>(rb[q], vb);
-          const float wq = s0 + q < HW ? 1.0f : 0.0f;
+          const float wq = s0 + q * nsub < HW ? 1.0f : 0.0f;
 #pragma unroll
           for (int j = 0; j < 8; ++j) { a[j] = fmaf(wq, va[j], a[j]); c[j] = fmaf(wq, vb[j], c[j]); }
         }
       }
+      if (nsub == 1) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        s_x[(c8 * 8 + j) * FB + fa] = a[j] * inv;
-        s_x[(c8 * 8 + j) * FB + fb] = c[j] * inv;
+        for (int j = 0; j < 8; ++j) {
+          s_x[(c8 * 8 + j) * FB + fa] = a[j] * inv;
+          s_x[(c8 * 8 + j) * FB + fb] = c[j] * inv;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          s_part[((size_t)fa * nsub + sub) * K + c8 * 8 + j] = a[j];
+          s_part[((size_t)fb * nsub + sub) * K + c8 * 8 + j] = c[j];
+        }
       }
+      if (nsub > 1) break;   // (one group per lane)
     }
   }
   __syncthreads();
+  if (nsub > 1) {
+    for (int i = tid; i < K * FB; i += 256) {
+      const int k = i / FB, f = i - k * FB;
+      float v = 0.f;
+      for (int q = 0; q < nsub; ++q) v += s_part[((size_t)f * nsub + q) * K + k];
+      s_x[i] = v * inv;
+    }
+    __syncthreads();
+  }
   // ---- y[f][n] = sum_k x[f][k] * wt[k][n]
   float acc[NPT][FB];
 #pragma unroll
@@ -618,6 +641,7 @@ __global__ __launch_bounds__(256) void gap_linear_norm_kernel(const typename TT:
 #pragma unroll
     for (int f = 0; f < FB; ++f) {
       acc[j][f] = acc[j][f] * sc + sh;
+      if (relu) acc[j][f] = fmaxf(acc[j][f], 0.f);
       ss[f] += acc[j][f] * acc[j][f];
     }
   }
@@ -644,16 +668,18 @@ __global__ __launch_bounds__(256) void gap_linear_norm_kernel(const typename TT:
   }
 }
 
-// wt: the Linear weight TRANSPOSED, fp32 [K][N] (N in {256, 512}); scale / shift: the folded BatchNorm1d ([N], may be NULL);
+// wt: the Linear weight TRANSPOSED, fp32 [K][N] (N in {256, 512}); scale / shift: the folded BatchNorm1d or the Linear bias ([N], may
+// be NULL); relu = 1: ReLU before the normalisation (BaselineNet: F.relu(self.fc1(pooled)), face_models.py:43-46);
 // pre_out / emb_out: [B][N] fp32 un-normalised / unit-norm embeddings (either may be NULL)
 extern "C" int frmap_gap_linear_norm(const void* map, const float* wt, const float* scale, const float* shift, float* pre_out,
-                                     float* emb_out, float eps, int B, int HW, int K, int N, int dtype, void* stream) {
+                                     float* emb_out, float eps, int B, int HW, int K, int N, int relu, int dtype, void* stream) {
   FRMAP_REQUIRE(map && wt && (pre_out || emb_out), "gap_linear_norm: null pointer");
   FRMAP_REQUIRE(dtype == FRMAP_BF16 || dtype == FRMAP_F16, "gap_linear_norm: bad dtype");
   FRMAP_REQUIRE(B > 0 && HW > 0 && K > 0 && K % 8 == 0 && K <= 2048, "gap_linear_norm: bad shape B=%d HW=%d K=%d", B, HW, K);
   FRMAP_REQUIRE(N == 256 || N == 512, "gap_linear_norm: N=%d not supported (256 or 512)", N);
   constexpr int FB = 8;
-  const size_t lds = (size_t)(K * FB + FB * 4) * sizeof(float);
+  const int c8n = K / 8, nsubh = c8n >= 64 ? 1 : 64 / c8n;
+  const size_t lds = (size_t)(K * FB + FB * 4 + (nsubh > 1 ? FB * nsubh * K : 0)) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((B + FB - 1) / FB);
   {
@@ -663,7 +689,7 @@ extern "C" int frmap_gap_linear_norm(const void* map, const float* wt, const flo
   }
 #define GLN_GO(TT, ET, NPT)                                                                                                  \
   hipLaunchKernelGGL((gap_linear_norm_kernel<TT, FB, NPT>), grid, dim3(256), lds, st, (const ET*)map, wt, scale, shift, pre_out, \
-                     emb_out, eps, B, HW, K)
+                     emb_out, eps, B, HW, K, relu)
   if (dtype == FRMAP_BF16) { if (N == 512) GLN_GO(BF16, __bf16, 2); else GLN_GO(BF16, __bf16, 1); }
   else { if (N == 512) GLN_GO(F16, _Float16, 2); else GLN_GO(F16, _Float16, 1); }
 #undef GLN_GO

@@ -293,17 +293,29 @@ class BaselineNet(_HipModule):
 
     def _build_plan(self, dtype):
         return {"c1": _PackedConv(self.conv1, self.bn1, dtype), "c2": _PackedConv(self.conv2, self.bn2, dtype),
-                "c3": _PackedConv(self.conv3, self.bn3, dtype)}
+                "c3": _PackedConv(self.conv3, self.bn3, dtype), "fc1_t": self.fc1.weight.detach().float().t().contiguous()}
 
-    def get_embedding(self, x):
+    def _embed(self, x):
+        """-> (embedding as the reference returns it, its unit-norm copy or None)."""
         x = self._check_input(x)
         p = self._get_plan()
         x = self._as_nhwc4(x)
         x = p["c1"].pooled(x)      # self.pool(F.relu(self.bn1(self.conv1(x)))), `face_models.py:38`
         x = p["c2"].pooled(x)
         x = p["c3"].pooled(x)
+        if _HEAD_FUSE:   # adaptive_pool + fc1 + ReLU (`face_models.py:41-46`) in one launch, the unit-norm copy for the matcher with it
+            emb, pre = ops.gap_linear_norm(x, p["fc1_t"], None, self.fc1.bias.detach(), 1e-12, want_pre=True, relu=True)
+            return pre, emb
         f = ops.avgpool_global(x)
-        return ops.linear_f32(f, self.fc1.weight.detach(), None, self.fc1.bias.detach(), relu=True)
+        return ops.linear_f32(f, self.fc1.weight.detach(), None, self.fc1.bias.detach(), relu=True), None
+
+    def get_embedding(self, x):
+        return self._embed(x)[0]
+
+    def unit_embedding(self, x):
+        """``F.normalize(get_embedding(x))`` (what `embed_and_match(normalize=True)` matches on) without a second launch."""
+        pre, emb = self._embed(x)
+        return emb if emb is not None else ops.l2_normalize(pre, 1e-12)
 
     def forward(self, x):
         e = self.get_embedding(x)

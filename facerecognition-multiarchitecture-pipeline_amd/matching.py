@@ -154,11 +154,14 @@ def embed_and_match(model, x: torch.Tensor, gallery, thresh: float = REC_THRESH,
         # embedding == global average pool of the trunk map (ResNetTransfer): pool + normalise + match in one launch
         _idx, dist, ids, pk, _ = ops.gap_norm_match(fmap, g.matrix if len(g) else None, thresh, normalize=normalize, packed=packed)
         return pk if (packed is not None and packed is not False) else (ids, dist)
-    emb = model.get_embedding(x)
-    if emb.dim() == 1:
-        emb = emb.unsqueeze(0)
-    if normalize:
-        emb = ops.l2_normalize(emb, 1e-12)
+    if normalize and hasattr(model, "unit_embedding"):
+        emb = model.unit_embedding(x)          # the head kernel's unit-norm output (BaselineNet)
+    else:
+        emb = model.get_embedding(x)
+        if emb.dim() == 1:
+            emb = emb.unsqueeze(0)
+        if normalize:
+            emb = ops.l2_normalize(emb, 1e-12)
     g = _as_gallery(gallery, emb.device)
     if packed is not None and packed is not False:
         return ops.match_top1(emb.to(torch.float32), g.matrix, thresh, packed=packed, prepared=g.prepared)[3]

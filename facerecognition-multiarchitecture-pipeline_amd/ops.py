@@ -548,7 +548,7 @@ def match_top1(emb: torch.Tensor, gallery: torch.Tensor, thresh: Optional[float]
 
 
 def gap_linear_norm(fmap: torch.Tensor, wt: torch.Tensor, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor],
-                    eps: float = 1e-12, want_pre: bool = False):
+                    eps: float = 1e-12, want_pre: bool = False, relu: bool = False):
     """ArcFaceNet head in one launch (`face_models.py:573-590`): global average pool of the NHWC trunk map [B,H,W,K] ->
     Linear (``wt`` = weight transposed, fp32 [K][N]) -> folded BatchNorm1d -> L2-normalise.  Returns ``(emb, pre | None)``."""
     fmap = _dev(fmap, "gap_linear_norm.map")
@@ -563,7 +563,7 @@ def gap_linear_norm(fmap: torch.Tensor, wt: torch.Tensor, scale: Optional[torch.
                                                  _dev(scale, "scale", torch.float32).data_ptr() if scale is not None else 0,
                                                  _dev(shift, "shift", torch.float32).data_ptr() if shift is not None else 0,
                                                  pre.data_ptr() if pre is not None else 0, emb.data_ptr(), float(eps),
-                                                 B, H * W, K, N, dt_code(fmap.dtype), _stream()), "gap_linear_norm")
+                                                 B, H * W, K, N, int(bool(relu)), dt_code(fmap.dtype), _stream()), "gap_linear_norm")
     return emb, pre
 
 

@@ -317,12 +317,14 @@ int frmap_match_top1_packed(const float* emb, const float* gallery, const void* 
 int frmap_gap_norm_match(const void* map, const float* gallery, float* emb_out, int32_t* idx_out, float* dist_out,
                          int32_t* id_or_unknown_out, int32_t* packed_out, float thresh, int normalize, float eps,
                          int B, int HW, int C, int G, int dtype, void* stream);
-/* ArcFaceNet head in one launch (src/face_models.py:573-590): AdaptiveAvgPool2d(1) of the NHWC trunk map
- * [B][HW][K] -> Linear(K, N, bias=False) -> BatchNorm1d(N) eval (folded: y * scale + shift) -> F.normalize(eps).
+/* Pool + Linear + normalise heads in one launch: AdaptiveAvgPool2d(1) of the NHWC trunk map [B][HW][K] -> Linear(K, N)
+ * (y * scale + shift: a folded BatchNorm1d, or scale = NULL and shift = the bias) -> optional ReLU -> F.normalize(eps).
+ *   ArcFaceNet (src/face_models.py:573-590): embedding (no bias) + bn, relu = 0;
+ *   BaselineNet (:41-46, 51-60): F.relu(self.fc1(pooled)), relu = 1 (pre_out = the reference's un-normalised embedding).
  * wt: the Linear weight transposed, fp32 [K][N], N in {256, 512}; pre_out / emb_out: fp32 [B][N] un-normalised /
  * unit-norm embeddings (either may be NULL). */
 int frmap_gap_linear_norm(const void* map, const float* wt, const float* scale, const float* shift, float* pre_out,
-                          float* emb_out, float eps, int B, int HW, int K, int N, int dtype, void* stream);
+                          float* emb_out, float eps, int B, int HW, int K, int N, int relu, int dtype, void* stream);
 int frmap_cosine_logits(const float* x, const float* w, float* logits_out, int32_t* argmax_out,
                         void* workspace, int B, int C, int D, float s, void* stream);
 int frmap_arcmargin_eval(const float* x, const float* w, const int64_t* label, float* logits_out,

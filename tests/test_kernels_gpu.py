@@ -605,6 +605,11 @@ def test_fused_arcface_head(dtype):
         assert torch.allclose(emb.norm(dim=1).cpu(), torch.ones(B), atol=1e-5)
         three = ops.l2_normalize(ops.linear_f32(ops.avgpool_global(fmap.to(DEV)), w.to(DEV), scale.to(DEV), shift.to(DEV)), 1e-12)
         assert torch.allclose(emb, three, atol=2e-6, rtol=2e-5), (ci, "fused and three-launch heads differ")
+        # BaselineNet's head (`face_models.py:41-46`): bias instead of the folded BatchNorm, ReLU before the normalisation
+        emb_r, pre_r = ops.gap_linear_norm(fmap.to(DEV), w.t().contiguous().to(DEV), None, shift.to(DEV), 1e-12, want_pre=True, relu=True)
+        pre_rr = F.relu((pooled.double() @ w.double().t()).float() + shift)
+        assert torch.allclose(pre_r.cpu(), pre_rr, atol=2e-5, rtol=2e-5), (ci, "relu head")
+        assert torch.allclose(emb_r.cpu(), F.normalize(pre_rr, p=2, dim=1, eps=1e-12), atol=2e-6, rtol=2e-5), (ci, "relu head, normalised")
     with pytest.raises(ValueError):
         ops.gap_linear_norm(torch.zeros(2, 7, 7, 512, dtype=dtype, device=DEV), torch.zeros(512, 384, device=DEV), None, None)
 
