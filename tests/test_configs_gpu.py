@@ -350,3 +350,29 @@ def test_device_resize_is_bit_exact_with_pillow(tmp_path):
     assert resize.resize_bilinear_u8([], (224, 224), "cuda").shape == (0, 224, 224, 3)
     with pytest.raises(ValueError):
         resize.resize_bilinear_u8([np.zeros((4, 4), np.uint8)], (224, 224), "cuda")
+
+
+def test_gallery_prepared_pack_lifecycle():
+    """`Gallery.prepared` (the fp16-split pack of the MFMA match path): absent below `ops.MATCH_MFMA_MIN_G` rows, built once,
+    rebuilt after an in-place edit of the gallery matrix, and `compare_faces` / `match_batch` through it agree with the
+    fp32 path on an enrolment-style gallery of 1 500 identities (first index wins on duplicated rows)."""
+    from frmap_amd import matching
+    small = frmap_amd.Gallery([f"s{i}" for i in range(100)], synth.unit_rows(71, 100, 512, "g"), "cuda")
+    assert small.prepared is None
+    rows = synth.unit_rows(72, 1500, 512, "g")
+    rows[900] = rows[7]                                   # a later duplicate of row 7
+    big = frmap_amd.Gallery([f"id{i}" for i in range(1500)], rows, "cuda")
+    p1 = big.prepared
+    assert p1 is not None and big.prepared is p1          # cached
+    probes = (rows[[7, 33, 1499]] + 2e-3 * synth.randn(73, (3, 512), "n")).cuda()
+    idx, dist = matching.match_batch(probes, big)
+    idx32, dist32 = ops.match_top1(probes, big.matrix)
+    assert idx.tolist() == [7, 33, 1499] and torch.equal(idx, idx32) and torch.equal(dist, dist32)
+    name, d, i = frmap_amd.compare_faces(probes[1:2].cpu(), big, 1.0)
+    assert (name, i) == ("id33", 33) and abs(d - float(dist[1])) < 1e-6
+    big.matrix[33] = big.matrix[34]                       # in-place edit: the pack must be rebuilt, row 33 no longer matches itself
+    p2 = big.prepared
+    assert p2 is not p1
+    idx2, _ = matching.match_batch(probes[1:2], big)
+    idx2_32, _ = ops.match_top1(probes[1:2], big.matrix)
+    assert torch.equal(idx2, idx2_32)
