@@ -51,6 +51,8 @@ def test_full_size_batch_properties():
         idx, dist = ops.match_top1(emb, gal)
         assert torch.equal(idx[:1000].cpu(), torch.arange(0, 10000, 10)[:1000].int())
         assert float((dist[:1000] - math.sqrt(512) * 1e-6).abs().max()) < 3e-6
+        idx_m, dist_m = ops.match_top1(emb, gal, prepared=ops.match_prepare(gal))   # the fp16-split MFMA path at full size
+        assert torch.equal(idx_m, idx) and torch.equal(dist_m, dist)
         # sharded == unsharded (8 ragged shards)
         parts = [ops.match_top1(emb[lo:hi], gal) for lo, hi in (fdist.shard_bounds(1024, r, 8) for r in range(8))]
         assert torch.equal(torch.cat([p[0] for p in parts]), idx) and torch.equal(torch.cat([p[1] for p in parts]), dist)
