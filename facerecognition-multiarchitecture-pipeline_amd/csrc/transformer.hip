@@ -368,7 +368,7 @@ extern "C" int frmap_mean_layernorm(const void* t, const float* gamma, const flo
 //   gate = sigmoid(conv KSxKS([mean_c y, max_c y]) + b)    (SpatialAttention, `:194-211`)
 //   map = y * gate ; pool = mean over positions            (+ AttentionNet's AdaptiveAvgPool2d(1), `:279`)
 // qkv is the packed projection [B][L][2*Cq + C] (q | k | v) a single 1x1 conv emits; thread t owns
-// channels t, t + 256, ... (CPT of them) of every position, so y never leaves registers, the channel
+// channels CPT t .. CPT t + CPT - 1 of every position (adjacent: one LDS read / one store per position), so y never leaves registers, the channel
 // mean / max are a wave reduction + 4-way LDS combine, and the final pooling is thread-local.
 // All arithmetic is fp32 on the storage-dtype inputs.
 // ================================================================================================
@@ -396,6 +396,7 @@ __global__ __launch_bounds__(256) void cnn_attention_kernel(const CnnAttnParams 
   float* part = at + LMAX * (LMAX + 1);  // [4 waves][2][LMAX] channel sum / max partials
   float* gate = part + 4 * 2 * LMAX;     // [LMAX] mean, [LMAX] max, [LMAX] gate
   elem* vs = (elem*)(gate + 3 * LMAX);   // [L][C] storage dtype
+  elem* xs = vs + (size_t)L * C;          // [L][C] the trunk map (residual input), staged with 16-byte loads
   const size_t b = blockIdx.x;
   const elem* qkv = (const elem*)p.qkv + b * (size_t)L * RS;
   const elem* xb = (const elem*)p.x + b * (size_t)L * C;
@@ -408,6 +409,7 @@ __global__ __launch_bounds__(256) void cnn_attention_kernel(const CnnAttnParams 
   for (int i = tid; i < L * (C / 8); i += 256) {
     const int r = i / (C / 8), c8 = i - r * (C / 8);
     *(u32x4_t*)(vs + (size_t)r * C + c8 * 8) = *(const u32x4_t*)(qkv + (size_t)r * RS + 2 * Cq + c8 * 8);
+    *(u32x4_t*)(xs + (size_t)r * C + c8 * 8) = *(const u32x4_t*)(xb + (size_t)r * C + c8 * 8);
   }
   __syncthreads();
   for (int e = tid; e < L * L; e += 256) {
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(256) void cnn_attention_kernel(const CnnAttnParams 
   for (int j = 0; j < L; ++j) {
     float vj[CPT];
 #pragma unroll
-    for (int cc = 0; cc < CPT; ++cc) vj[cc] = TT::to_f32(vs[(size_t)j * C + tid + 256 * cc]);
+    for (int cc = 0; cc < CPT; ++cc) vj[cc] = TT::to_f32(vs[(size_t)j * C + tid * CPT + cc]);   // CPT adjacent channels: one LDS read
 #pragma unroll
     for (int i = 0; i < LMAX; ++i) {
       const float a = i < L ? at[i * (LMAX + 1) + j] : 0.f;  // same address in every lane: an LDS broadcast
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(256) void cnn_attention_kernel(const CnnAttnParams 
     if (i < L) {
 #pragma unroll
       for (int cc = 0; cc < CPT; ++cc) {
-        y[i][cc] = fmaf(gamma, y[i][cc], TT::to_f32(xb[(size_t)i * C + tid + 256 * cc]));
+        y[i][cc] = fmaf(gamma, y[i][cc], TT::to_f32(xs[(size_t)i * C + tid * CPT + cc]));
         s += y[i][cc];
         m = fmaxf(m, y[i][cc]);
       }
@@ -500,22 +502,29 @@ __global__ __launch_bounds__(256) void cnn_attention_kernel(const CnnAttnParams 
   for (int i = 0; i < LMAX; ++i)
     if (i < L) {
       const float gt = gate[2 * LMAX + i];
+      float ov[CPT];
 #pragma unroll
       for (int cc = 0; cc < CPT; ++cc) {
         const float o = y[i][cc] * gt;
         pool[cc] += o;
-        if (om) om[(size_t)i * C + tid + 256 * cc] = TT::from_f32(o);
+        ov[cc] = o;
+      }
+      if (om) {
+        if (CPT == 2) *(unsigned*)(om + (size_t)i * C + tid * 2) = pack4<TT>(ov[0], ov[CPT - 1], 0.f, 0.f)[0];
+        else
+#pragma unroll
+          for (int cc = 0; cc < CPT; ++cc) om[(size_t)i * C + tid * CPT + cc] = TT::from_f32(ov[cc]);
       }
     }
   if (p.out_pool)
 #pragma unroll
-    for (int cc = 0; cc < CPT; ++cc) p.out_pool[b * C + tid + 256 * cc] = pool[cc] / (float)L;
+    for (int cc = 0; cc < CPT; ++cc) p.out_pool[b * C + tid * CPT + cc] = pool[cc] / (float)L;
 }
 
 template <typename TT, int CPT, int LMAX>
 static int cnn_attention_launch(const CnnAttnParams& p, hipStream_t st) {
   const size_t lds = (size_t)(2 * LMAX * (p.Cq + 1) + LMAX * (LMAX + 1) + 8 * LMAX + 3 * LMAX) * sizeof(float) +
-                     (size_t)p.L * p.C * sizeof(typename TT::elem);
+                     (size_t)2 * p.L * p.C * sizeof(typename TT::elem);
   FRMAP_REQUIRE(lds <= 160 * 1024, "cnn_attention: %zu bytes of LDS needed (> 160 KB)", lds);
   auto kern = cnn_attention_kernel<TT, CPT, LMAX>;
   if (frmap_big_lds((const void*)kern, 160 * 1024)) return -2;
