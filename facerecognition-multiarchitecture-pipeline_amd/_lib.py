@@ -13,7 +13,7 @@ import threading
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libfrmap_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lock = threading.Lock()
 _lib = None
@@ -68,6 +68,7 @@ PROTOTYPES = {
     "frmap_softmax_argmax": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "frmap_pairwise_distance": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
     "frmap_head_workspace_bytes": (_sz, [_i, _i]),
+    "frmap_match_workspace_bytes": (_sz, [_i, _i]),
     "frmap_match_top1": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "frmap_gap_norm_match": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _f, _i, _i, _i, _i, _i, _vp]),
     "frmap_cosine_logits": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),

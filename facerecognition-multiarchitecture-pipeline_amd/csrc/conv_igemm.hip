@@ -49,7 +49,7 @@ struct ConvParams {
   // conv1x1_kernel<..., MATCH = true>: the GEMM is probes x gallery rows, the epilogue keeps each probe's arg-min distance
   const float* m_stat_a;           // [M][4] = (sum a^2, sum a, 1 / row scale, row scale) of the fp32 probes
   const float* m_stat_w;           // [G][4] of the fp32 gallery rows
-  unsigned long long* m_keys;      // [M] packed (bits(d^2) << 32 | row), atomicMin
+  MatchRec* m_recs;                // [Cout / 64][M] candidate records (frmap_common.h), one writer each
   int m_G, m_D;                    // real gallery rows (Cout is padded to 64), embedding width
 };
 
@@ -1013,7 +1013,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_fast_kernel(const ConvParams
 // MATCH = true: top-1 gallery match (head_match.hip, frmap_match_top1_packed).  The "pixels" are the probes and the
 // "channels" the gallery rows, both split into fp16 (hi, lo) pairs laid out so that one K = 3 D GEMM accumulates
 // a_hi.g_hi + a_hi.g_lo + a_lo.g_hi in fp32 (= the fp32 dot product to ~2^-22); the epilogue forms the squared
-// F.pairwise_distance from it exactly as gemm_nt_f32_kernel<MODE_DIST> does and keeps one (distance, row) key per probe.
+// F.pairwise_distance from it as gemm_nt_f32_kernel<MODE_DIST> does and writes one candidate record per probe and 64-row slot.
 template <typename TT, int CKS, bool MATCH = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const ConvParams p) {
   constexpr int BM = 256, MI = 4, NI = 4, NIT = BM * 4 / 256;
@@ -1088,40 +1088,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const ConvParams p) {
     }
   }
   if constexpr (MATCH) {
-    // lane: probe column lr of pixel group mi, gallery rows (nt * 64 + ni * 16 + 4 g + j): ascending row order inside the
-    // lane, strict < keeps the first minimum; the 4 lanes of a column meet through two shuffles; one atomic per probe
-    float w2[NI][4], ws[NI][4], wi[NI][4];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = min((nt << 6) + ni * 16 + 4 * g + j, p.m_G - 1);
-        const f32x4_t sw = *(const f32x4_t*)(p.m_stat_w + 4 * (size_t)n);
-        w2[ni][j] = sw[0]; ws[ni][j] = sw[1]; wi[ni][j] = sw[2];
-      }
-    const float eps = 1e-6f, keps = (float)p.m_D * eps * eps;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int b = m0 + wave * 64 + mi * 16 + lr;
-      const f32x4_t sa = *(const f32x4_t*)(p.m_stat_a + 4 * (size_t)min(b, p.M - 1));
-      const float a2 = sa[0], as = sa[1], ai = sa[2];
-      unsigned long long key = ~0ull;
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int n = (nt << 6) + ni * 16 + 4 * g + j;
-          float d2 = a2 + w2[ni][j] - 2.f * (acc[mi][ni][j] * ai * wi[ni][j]) + 2.f * eps * (as - ws[ni][j]) + keps;
-          d2 = fmaxf(d2, 0.f);
-          const unsigned long long k2 = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)n;
-          if (n < p.m_G && k2 < key) key = k2;
-        }
-      unsigned long long o = __shfl_xor(key, 16, 64);
-      key = o < key ? o : key;
-      o = __shfl_xor(key, 32, 64);
-      key = o < key ? o : key;
-      if (g == 0 && b < p.M && key != ~0ull) atomicMin(p.m_keys + b, key);
-    }
+    match_epilogue_records<MI>(acc, m0 + wave * 64, p.M, nt << 6, p.m_G, p.m_D, p.M, p.m_stat_a, p.m_stat_w, p.m_recs, lane);
     return;
   }
   __syncthreads();
@@ -1493,11 +1460,11 @@ extern "C" int frmap_conv_igemm_pool2(const void* in, const void* w_packed, cons
 // power-of-two scale, whose inverse is the third float of its statistics record.
 // ------------------------------------------------------------------------------------------------
 int frmap_match_gemm_f16x3(const void* probes3, const void* gallery_packed, const float* stat_a, const float* stat_w,
-                           unsigned long long* keys, int B, int G, int D, hipStream_t st) {
+                           MatchRec* recs, int B, int G, int D, hipStream_t st) {
   const int K3 = 3 * D, Gpad = (G + 255) / 256 * 256;   // (the packed gallery is padded to 256 rows: frmap_match_gallery_pack_bytes)
   FRMAP_REQUIRE(K3 % 32 == 0, "match: D=%d must be a multiple of 32", D);
   {
-    const int rc = frmap_match_gemm_pp(probes3, gallery_packed, stat_a, stat_w, keys, B, G, Gpad, D, st);
+    const int rc = frmap_match_gemm_pp(probes3, gallery_packed, stat_a, stat_w, recs, B, G, Gpad, D, st);
     if (rc < 0) return rc;
     if (rc == 1) return 0;
   }
@@ -1511,7 +1478,7 @@ int frmap_match_gemm_f16x3(const void* probes3, const void* gallery_packed, cons
   p.dHoWo = frmap_div_make(1u); p.dWo = frmap_div_make(1u);
   p.ksplit = 1;
   p.nblocks = ((B + 255) / 256) * (Gpad / 64);
-  p.m_stat_a = stat_a; p.m_stat_w = stat_w; p.m_keys = keys; p.m_G = G; p.m_D = D;
+  p.m_stat_a = stat_a; p.m_stat_w = stat_w; p.m_recs = recs; p.m_G = G; p.m_D = D;
   const int c32 = K3 / 32;
   if (c32 % 4 == 0) { p.nchunks = c32 / 4; return launch_1x1<F16, 4, true>(p, st); }
   if (c32 % 2 == 0) { p.nchunks = c32 / 2; return launch_1x1<F16, 2, true>(p, st); }

@@ -57,7 +57,7 @@ struct PPParams {
   // conv1x1_pp_kernel<..., MATCH = true> (top-1 gallery match, head_match.hip): per-row statistics and the arg-min keys
   const float* m_stat_a;        // [M][4] = (sum a^2, sum a, 1 / row scale, row scale) of the fp32 probes
   const float* m_stat_w;        // [G][4] of the fp32 gallery rows
-  unsigned long long* m_keys;   // [M] packed (bits(d^2) << 32 | row), atomicMin
+  MatchRec* m_recs;             // [Cout / 64][M] candidate records (frmap_common.h), one writer each
   int m_G, m_D;
 };
 
@@ -507,8 +507,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p) {
 // few tiles (Linear 2048 -> 512 over 12 544 tokens: 224 tiles instead of 112).
 // ================================================================================================
 // MATCH = true: the epilogue of conv1x1_kernel<..., MATCH> (conv_igemm.hip): the GEMM is probes x gallery rows in split fp16
-// operands, each lane forms the expanded squared F.pairwise_distance of its 16 gallery rows, the column's four lanes meet
-// through two shuffles, one 64-bit atomicMin per probe and tile.
+// operands, each lane forms the expanded squared F.pairwise_distance of its 16 gallery rows with its error band, the column's
+// four lanes meet through two shuffles, one candidate record per probe and 64-row slot (match_epilogue_records).
 template <typename TT, int MI, int WM, int KS, bool MATCH = false>
 __global__ __launch_bounds__(512, 2) void conv1x1_pp_kernel(const PPParams p) {
   constexpr int NI = 4, WN = KS == 2 ? 2 : 8 / WM;
@@ -639,39 +639,8 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pp_kernel(const PPParams p) {
     if (grp == 1) return;
   }
   if constexpr (MATCH) {
-    const int n0 = nt * BN + wn * 64;
-    float w2[NI][4], ws[NI][4], wi[NI][4];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = min(n0 + ni * 16 + 4 * g + j, p.m_G - 1);
-        const f32x4_t sw = *(const f32x4_t*)(p.m_stat_w + 4 * (size_t)n);
-        w2[ni][j] = sw[0]; ws[ni][j] = sw[1]; wi[ni][j] = sw[2];
-      }
-    const float eps = 1e-6f, keps = (float)p.m_D * eps * eps;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int b = m0 + mslice * (MI * 16) + mi * 16 + lr;
-      const f32x4_t sa = *(const f32x4_t*)(p.m_stat_a + 4 * (size_t)min(b, p.M - 1));
-      const float a2 = sa[0], as = sa[1], ai = sa[2];
-      unsigned long long key = ~0ull;
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int n = n0 + ni * 16 + 4 * g + j;
-          float d2 = a2 + w2[ni][j] - 2.f * (acc[mi][ni][j] * ai * wi[ni][j]) + 2.f * eps * (as - ws[ni][j]) + keps;
-          d2 = fmaxf(d2, 0.f);
-          const unsigned long long k2 = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)n;
-          if (n < p.m_G && k2 < key) key = k2;
-        }
-      unsigned long long o = __shfl_xor(key, 16, 64);
-      key = o < key ? o : key;
-      o = __shfl_xor(key, 32, 64);
-      key = o < key ? o : key;
-      if (g == 0 && b < mend && key != ~0ull) atomicMin(p.m_keys + b, key);
-    }
+    match_epilogue_records<MI>(acc, m0 + mslice * (MI * 16), mend, nt * BN + wn * 64, p.m_G, p.m_D, p.M, p.m_stat_a, p.m_stat_w,
+                               p.m_recs, lane);
     return;
   }
   conv_epilogue<TT, MI, NI>(acc, smem + (KS == 2 ? q : wave) * (16 * (NI * 64 + 16)), m0 + mslice * (MI * 16), mend, p.Cout,
@@ -1204,7 +1173,7 @@ int frmap_conv1x1_pp(const void* in, const void* w_packed, const float* shift, c
 // top-1 match GEMM on the same kernel (see frmap_match_gemm_f16x3 in conv_igemm.hip): G padded to 256 rows, K3 = 3 D.
 // 1 = launched, 0 = not taken
 int frmap_match_gemm_pp(const void* probes3, const void* gallery_packed, const float* stat_a, const float* stat_w,
-                        unsigned long long* keys, int B, int G, int Gpad, int D, hipStream_t st) {
+                        MatchRec* recs, int B, int G, int Gpad, int D, hipStream_t st) {
   static int on = -1;
   if (on < 0) on = pp_env("FRMAP_CONV_PP", 1) && pp_env("FRMAP_MATCH_PP", 1);
   const int K3 = 3 * D;
@@ -1217,7 +1186,7 @@ int frmap_match_gemm_pp(const void* probes3, const void* gallery_packed, const f
   p.magic_Wp = frmap_magic(1u); p.magic_Hp = frmap_magic(1u);
   p.dHoWo = frmap_div_make(1u); p.dWo = frmap_div_make(1u); p.dWo2 = frmap_div_make(1u);
   p.nchunks = K3 / 32; p.ds_stride = 1;
-  p.m_stat_a = stat_a; p.m_stat_w = stat_w; p.m_keys = keys; p.m_G = G; p.m_D = D;
+  p.m_stat_a = stat_a; p.m_stat_w = stat_w; p.m_recs = recs; p.m_G = G; p.m_D = D;
   // 224 probes x 256 gallery rows per tile, or 448 x 128 when that fills the CUs better (one round either way at 1024 probes)
   const long long t1 = ((B + 223) / 224) * (long long)(Gpad / 256), t2 = ((B + 447) / 448) * (long long)(Gpad / 128);
   const long long r1 = (t1 + 255) / 256, r2 = (t2 + 255) / 256;   // rounds on 256 CUs (a tile costs the same in both layouts)

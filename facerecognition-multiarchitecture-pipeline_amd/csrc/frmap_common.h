@@ -65,6 +65,87 @@ __device__ __forceinline__ u32x4_t pack8(const float* f) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Top-1 gallery match (compare_faces, /root/reference/src/app.py:58-63) behind a GEMM: candidate records.
+//
+// The GEMM kernels score a (probe, gallery row) pair by the EXPANDED squared distance
+//     d2e = |a|^2 + |g|^2 - 2 a.g + 2 eps (sum a - sum g) + K eps^2        (eps = 1e-6, F.pairwise_distance's)
+// whose rounding error is bounded by  delta(a, g) = kappa * (band(a) + band(g) + K eps^2),
+//     band(x) = |x|^2 + 2 eps sqrt(K |x|^2)  (>= |x|^2 + 2 eps sum |x_i|),  kappa = (2 T + 64) * 2^-24,
+// T = the number of products the dot product accumulates (K for the fp32 GEMM, 3 K for the split-fp16 GEMM whose
+// operands carry another 3 * 2^-22 of relative error): a worst-case bound (gamma_T * sum |a_i g_i| <= T u (|a|^2 + |g|^2) / 2
+// for the dot product, the same for the two squared norms, a few u for the combination), not a typical-case one.
+// So with L = d2e - delta and U = d2e + delta, the row that minimises the EXACT distance has L <= min over all rows of U.
+// An epilogue therefore writes, per probe and per SLOT of consecutive gallery rows, one record
+//     (lo1, idx) = smallest L of the slot and its row,  lo2 = second smallest L,  up = smallest U
+// (no atomics: every record has exactly one writer), and match_finalize_rec_kernel (head_match.hip) re-scores with the exact
+// ||(a - g) + eps||_2 every slot whose lo1 <= min up: its single row when lo2 is outside the band, all of its rows otherwise,
+// and keeps the first strict minimum - the reference loop's answer, not the expanded form's.
+// ------------------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) MatchRec {
+  float lo1;
+  int idx;
+  float lo2;
+  float up;
+};
+__device__ __forceinline__ float match_kappa(int terms) { return (float)(2 * terms + 64) * 5.9604644775390625e-8f; }
+__device__ __forceinline__ float match_band(float s2, float kf) { return s2 + 2e-6f * sqrtf(kf * s2); }
+
+// Epilogue of the split-fp16 match GEMMs (conv1x1_kernel<.., MATCH>, conv1x1_pp_kernel<.., MATCH>): after the K loop lane
+// (lr, g) holds, per MFMA tile (mi, ni), the scaled dot products of probe b_base + mi * 16 + lr with gallery rows
+// n0 + ni * 16 + 4 g + j.  The wave's 64 gallery rows are one slot (n0 / 64); records are laid out [slot][M].
+template <int MI>
+__device__ __forceinline__ void match_epilogue_records(const f32x4_t (&acc)[MI][4], int b_base, int b_end, int n0, int G, int D,
+                                                       int M, const float* __restrict__ stat_a,
+                                                       const float* __restrict__ stat_w, MatchRec* __restrict__ recs,
+                                                       int lane) {
+  const int lr = lane & 15, g = lane >> 4;
+  const float eps = 1e-6f, kf = (float)D, keps = kf * eps * eps, kap = match_kappa(3 * D);
+  float w2[4][4], ws[4][4], wi[4][4], wb[4][4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = min(n0 + ni * 16 + 4 * g + j, G - 1);
+      const f32x4_t sw = *(const f32x4_t*)(stat_w + 4 * (size_t)n);
+      w2[ni][j] = sw[0]; ws[ni][j] = sw[1]; wi[ni][j] = sw[2];
+      wb[ni][j] = match_band(sw[0], kf) + keps;
+    }
+  MatchRec* out = recs + (size_t)(n0 >> 6) * M;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int b = b_base + mi * 16 + lr;
+    const f32x4_t sa = *(const f32x4_t*)(stat_a + 4 * (size_t)min(b, M - 1));
+    const float a2 = sa[0], as = sa[1], ai = sa[2], ab = match_band(sa[0], kf);
+    float l1 = INFINITY, l2 = INFINITY, up = INFINITY;
+    int i1 = -1;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + ni * 16 + 4 * g + j;
+        const float d2 = a2 + w2[ni][j] - 2.f * (acc[mi][ni][j] * ai * wi[ni][j]) + 2.f * eps * (as - ws[ni][j]) + keps;
+        const float dl = kap * (ab + wb[ni][j]);
+        const float L = n < G ? d2 - dl : INFINITY, U = n < G ? d2 + dl : INFINITY;
+        if (L < l1) { l2 = l1; l1 = L; i1 = n; }   // rows ascend inside the lane: the first of equal L keeps the index,
+        else if (L < l2) l2 = L;                   // the second lands in lo2 (= lo1: the whole slot is re-scored)
+        up = fminf(up, U);
+      }
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+      const float ol1 = __shfl_xor(l1, o, 64), ol2 = __shfl_xor(l2, o, 64), ou = __shfl_xor(up, o, 64);
+      const int oi1 = __shfl_xor(i1, o, 64);
+      const float nl2 = fminf(fminf(l2, ol2), fmaxf(l1, ol1));
+      if (ol1 < l1) { l1 = ol1; i1 = oi1; }
+      l2 = nl2; up = fminf(up, ou);
+    }
+    if (g == 0 && b < b_end) {
+      MatchRec r; r.lo1 = l1; r.idx = i1; r.lo2 = l2; r.up = up;
+      out[b] = r;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Shared conv epilogue.  After the K loop a lane holds, per 16x16 MFMA tile (mi, ni), 4 consecutive
 // output channels (ni*16 + g*4 ..+3) of ONE pixel (mi*16 + lr).  Storing that directly is 8 bytes
 // per lane scattered over 16 pixel rows per instruction (32-byte fragments of 128-byte lines).
@@ -281,10 +362,10 @@ int frmap_conv3x3_pp_pool(const void* in, const void* w_packed, const float* shi
 int frmap_conv1x1_pp(const void* in, const void* w_packed, const float* shift, const void* residual, void* out, int B, int Hi,
                      int Wi, int Cin, int Cout, int stride, int relu, int dtype, hipStream_t st);
 int frmap_match_gemm_pp(const void* probes3, const void* gallery_packed, const float* stat_a, const float* stat_w,
-                        unsigned long long* keys, int B, int G, int Gpad, int D, hipStream_t st);
+                        MatchRec* recs, int B, int G, int Gpad, int D, hipStream_t st);
 // top-1 match GEMM on the 1x1 MFMA kernel (conv_igemm.hip), see frmap_match_top1_packed
 int frmap_match_gemm_f16x3(const void* probes3, const void* gallery_packed, const float* stat_a, const float* stat_w,
-                           unsigned long long* keys, int B, int G, int D, hipStream_t st);
+                           MatchRec* recs, int B, int G, int D, hipStream_t st);
 #define FRMAP_REQUIRE(cond, ...)        \
   do {                                  \
     if (!(cond)) {                      \

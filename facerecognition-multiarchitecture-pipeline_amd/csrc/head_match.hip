@@ -33,6 +33,7 @@ struct GemmEpi {
   // DIST
   const float* stat_a;  // [B][2] = (sum x^2, sum x)
   const float* stat_w;  // [N][2]
+  MatchRec* recs;       // [4 * gridDim.x][B] candidate records, slot = 32 gallery rows (one wave's columns)
   float* out;           // [B][N] or null
 };
 
@@ -66,6 +67,20 @@ __device__ __forceinline__ float half_wave_best(float v, int lk, int& first_li) 
   const unsigned half = lk ? (unsigned)(hit >> 32) : (unsigned)hit;
   first_li = __ffs(half) - 1;  // >= 0: the lane(s) that contributed m are in the mask
   return m;
+}
+
+// plain minimum over the 32 lanes of this lane's half-wave (same DPP ladder, no index)
+__device__ __forceinline__ float half_wave_min(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    const int i = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, decltype(ctrl)::value, 0xF, 0xF, false));
+  };
+  float m = v;
+  m = fminf(m, dpp(m, std::integral_constant<int, 0xB1>{}));
+  m = fminf(m, dpp(m, std::integral_constant<int, 0x4E>{}));
+  m = fminf(m, dpp(m, std::integral_constant<int, 0x141>{}));
+  m = fminf(m, dpp(m, std::integral_constant<int, 0x140>{}));
+  return fminf(m, __shfl_xor(m, 16, 64));
 }
 
 template <int MODE>
@@ -124,7 +139,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
   const int n = n0 + wave * 32 + li;
   const bool nvalid = n < N;
   float cmax = -INFINITY, cmin = INFINITY;
-  float wscale = 1.f, wshift = 0.f, winv = 0.f, wn2 = 0.f, wsum = 0.f;
+  float wscale = 1.f, wshift = 0.f, winv = 0.f, wn2 = 0.f, wsum = 0.f, wband = 0.f;
   if (nvalid) {
     if (MODE == MODE_LINEAR) {
       wscale = ep.scale ? ep.scale[n] : 1.f;
@@ -132,6 +147,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
     } else if (MODE == MODE_DIST) {
       wn2 = ep.stat_w[2 * n];
       wsum = ep.stat_w[2 * n + 1];
+      wband = match_band(wn2, (float)K);
     } else {
       winv = ep.inv_w[n];
     }
@@ -182,24 +198,27 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
           if (isnan(v) || isinf(v)) v = 0.f;
           ep.out[(size_t)b * N + n] = v;
         }
-      } else {  // MODE_DIST: ||a - g + eps||^2 = |a|^2 + |g|^2 - 2 a.g + 2 eps (sum a - sum g) + K eps^2
-        float d2 = INFINITY;  // columns / rows outside the problem never win
+      } else {  // MODE_DIST: ||a - g + eps||^2 = |a|^2 + |g|^2 - 2 a.g + 2 eps (sum a - sum g) + K eps^2, with its error band
+        float L = INFINITY, U = INFINITY;  // columns / rows outside the problem never become candidates
         if (valid) {
-          const float eps = 1e-6f;
-          d2 = ep.stat_a[2 * b] + wn2 - 2.f * dot + 2.f * eps * (ep.stat_a[2 * b + 1] - wsum) + (float)K * eps * eps;
-          d2 = fmaxf(d2, 0.f);
+          const float eps = 1e-6f, kf = (float)K, keps = kf * eps * eps;
+          const float sa2 = ep.stat_a[2 * b];
+          const float d2 = sa2 + wn2 - 2.f * dot + 2.f * eps * (ep.stat_a[2 * b + 1] - wsum) + keps;
+          const float dl = match_kappa(K) * (match_band(sa2, kf) + wband + keps);
+          L = d2 - dl; U = d2 + dl;
         }
         int fl;
-        const float best = half_wave_best<false>(d2, lk, fl);
-        if (li == 0) {
-          const int nb = n0 + wave * 32 + fl;
-          s_key[wave * BMr + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk] =
-              (b < B && best < INFINITY) ? (((unsigned long long)__float_as_uint(best) << 32) | (unsigned)nb) : ~0ull;
+        const float l1 = half_wave_best<false>(L, lk, fl);
+        const float l2 = half_wave_min(li == fl ? INFINITY : L);
+        const float up = half_wave_min(U);
+        if (li == 0 && b < B) {
+          MatchRec r; r.lo1 = l1; r.idx = l1 < INFINITY ? n0 + wave * 32 + fl : -1; r.lo2 = l2; r.up = up;
+          ep.recs[(size_t)(blockIdx.x * 4 + wave) * B + b] = r;
         }
       }
     }
   }
-  if ((MODE == MODE_DIST || MODE == MODE_COS) && ep.argkey) {
+  if (MODE == MODE_COS && ep.argkey) {
     // the four waves' candidates per row meet in LDS: one atomic per row and workgroup instead of one per row and wave
     __syncthreads();
     if (tid < BMr && b0 + tid < B) {
@@ -207,10 +226,9 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
 #pragma unroll
       for (int w = 1; w < 4; ++w) {
         const unsigned long long o = s_key[w * BMr + tid];
-        key = MODE == MODE_DIST ? (o < key ? o : key) : (o > key ? o : key);
+        key = o > key ? o : key;
       }
-      if (MODE == MODE_DIST) { if (key != ~0ull) atomicMin(ep.argkey + b0 + tid, key); }
-      else if (key) atomicMax(ep.argkey + b0 + tid, key);
+      if (key) atomicMax(ep.argkey + b0 + tid, key);
     }
   }
   if (MODE == MODE_ARC && ep.minmax_key) {
@@ -275,34 +293,68 @@ __global__ void fill_u64_kernel(unsigned long long* p, int n, unsigned long long
   if (i < n) p[i] = v;
 }
 
-// exact distance of the winner, the way F.pairwise_distance forms it: ||(a - g) + eps||_2 in fp32
-__global__ void match_finalize_kernel(const float* __restrict__ emb, const float* __restrict__ gal,
-                                      const unsigned long long* __restrict__ keys, int32_t* __restrict__ idx_out,
-                                      float* __restrict__ dist_out, int32_t* __restrict__ id_thr_out,
-                                      int32_t* __restrict__ packed_out, float thresh, int B, int G, int D) {
-  const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-  if (b >= B) return;
-  const unsigned long long key = keys[b];
-  if (G <= 0 || key == ~0ull) {
-    if (lane == 0) {
-      idx_out[b] = -1; dist_out[b] = INFINITY;
-      if (id_thr_out) id_thr_out[b] = -1;
-      if (packed_out) { packed_out[2 * b] = -1; packed_out[2 * b + 1] = __float_as_int(INFINITY); }
+// ||(a - g) + eps||_2^2 the way F.pairwise_distance forms its elements (fp32 subtract, fp32 add of eps), squares summed in
+// float64 by the whole wave: the result does not depend on a summation order, identical rows give identical values, and it
+// is within 2^-24 of what any fp32 summation of the same 512 squares returns.  Every lane gets the sum.
+__device__ __forceinline__ double match_exact_d2(const float* __restrict__ a, const float* __restrict__ g, int D, int lane) {
+  double s2 = 0.0;
+  for (int k = lane * 4; k < D; k += 256) {
+    const f32x4_t av = *(const f32x4_t*)(a + k), gv = *(const f32x4_t*)(g + k);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float d = (av[j] - gv[j]) + 1e-6f;
+      s2 += (double)d * (double)d;
     }
-    return;
-  }
-  const int g = (int)(key & 0xFFFFFFFFull);
-  float s2 = 0.f;
-  for (int k = lane; k < D; k += 64) {
-    const float d = (emb[(size_t)b * D + k] - gal[(size_t)g * D + k]) + 1e-6f;
-    s2 += d * d;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+  return s2;
+}
+
+// One wave per probe.  Reads the probe's candidate records (frmap_common.h: MatchRec [nslots][B], slot = slot_w consecutive
+// gallery rows), takes ug = min over slots of `up`, and re-scores with the exact distance every slot whose lo1 <= ug: the
+// slot's single candidate row when its second-best bound lies outside the band, every row of the slot otherwise.  Slots and
+// rows are visited in ascending order and only a strictly smaller distance replaces the best one, so the result is the
+// FIRST row attaining the minimum of the exact distance: compare_faces' loop (/root/reference/src/app.py:58-63).
+__global__ void match_finalize_rec_kernel(const float* __restrict__ emb, const float* __restrict__ gal,
+                                          const MatchRec* __restrict__ recs, int nslots, int slot_w,
+                                          int32_t* __restrict__ idx_out, float* __restrict__ dist_out,
+                                          int32_t* __restrict__ id_thr_out, int32_t* __restrict__ packed_out, float thresh,
+                                          int B, int G, int D) {
+  const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (b >= B) return;
+  const float* a = emb + (size_t)b * D;
+  float ug = INFINITY;
+  for (int s = lane; s < nslots; s += 64) ug = fminf(ug, recs[(size_t)s * B + b].up);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ug = fminf(ug, __shfl_xor(ug, o, 64));
+  double best = INFINITY;
+  int besti = -1;
+  for (int s0 = 0; s0 < nslots; s0 += 64) {
+    MatchRec r; r.lo1 = INFINITY; r.idx = -1; r.lo2 = INFINITY; r.up = INFINITY;
+    if (s0 + lane < nslots) r = recs[(size_t)(s0 + lane) * B + b];
+    unsigned long long mask = __ballot(r.lo1 <= ug && r.idx >= 0);
+    while (mask) {
+      const int l = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      const int ci = __shfl(r.idx, l, 64);
+      const float l2 = __shfl(r.lo2, l, 64);
+      if (l2 <= ug) {
+        const int g0 = (s0 + l) * slot_w, g1 = min(g0 + slot_w, G);
+        for (int g = g0; g < g1; ++g) {
+          const double d = match_exact_d2(a, gal + (size_t)g * D, D, lane);
+          if (d < best) { best = d; besti = g; }
+        }
+      } else {
+        const double d = match_exact_d2(a, gal + (size_t)ci * D, D, lane);
+        if (d < best) { best = d; besti = ci; }
+      }
+    }
+  }
   if (lane == 0) {
-    const float d = sqrtf(s2);
-    idx_out[b] = g; dist_out[b] = d;
-    const int idt = d <= thresh ? g : -1;
+    const float d = besti >= 0 ? (float)sqrt(best) : INFINITY;
+    idx_out[b] = besti; dist_out[b] = d;
+    const int idt = (besti >= 0 && d <= thresh) ? besti : -1;
     if (id_thr_out) id_thr_out[b] = idt;
     if (packed_out) { packed_out[2 * b] = idt; packed_out[2 * b + 1] = __float_as_int(d); }
   }
@@ -810,20 +862,25 @@ extern "C" int frmap_match_top1(const float* emb, const float* gallery, int32_t*
     FRMAP_LAUNCH_CHECK();
     return 0;
   }
-  unsigned long long* keys = (unsigned long long*)workspace;
-  float* stat_a = (float*)(keys + B);
-  float* stat_w = stat_a + 2 * (size_t)B;
-  hipLaunchKernelGGL(fill_u64_kernel, dim3((B + 255) / 256), dim3(256), 0, st, keys, B, ~0ull);
-  if (G > 0) {
-    hipLaunchKernelGGL(row_stats_kernel, dim3(waves_blocks(B)), dim3(256), 0, st, emb, stat_a, B, D, 1, 0.f);
-    hipLaunchKernelGGL(row_stats_kernel, dim3(waves_blocks(G)), dim3(256), 0, st, gallery, stat_w, G, D, 1, 0.f);
-    GemmEpi ep = {};
-    ep.stat_a = stat_a; ep.stat_w = stat_w; ep.argkey = keys;
-    int rc = launch_gemm<MODE_DIST>(emb, gallery, B, G, D, ep, st);
-    if (rc) return rc;
+  if (G <= 0) {
+    hipLaunchKernelGGL(match_finalize_rec_kernel, dim3(waves_blocks(B)), dim3(256), 0, st, emb, gallery, (const MatchRec*)nullptr, 0, 32,
+                       idx_out, dist_out, id_or_unknown_out, packed_out, thresh, B, 0, D);
+    FRMAP_LAUNCH_CHECK();
+    return 0;
   }
-  hipLaunchKernelGGL(match_finalize_kernel, dim3(waves_blocks(B)), dim3(256), 0, st, emb, gallery, keys, idx_out, dist_out,
-                     id_or_unknown_out, packed_out, thresh, B, G, D);
+  // workspace (frmap_match_workspace_bytes): records [4 * ceil(G / 128)][B] | probe statistics [B][2] | gallery statistics [G][2]
+  const int nslots = 4 * ((G + 127) / 128);
+  MatchRec* recs = (MatchRec*)workspace;
+  float* stat_a = (float*)(recs + (size_t)nslots * B);
+  float* stat_w = stat_a + 2 * (size_t)B;
+  hipLaunchKernelGGL(row_stats_kernel, dim3(waves_blocks(B)), dim3(256), 0, st, emb, stat_a, B, D, 1, 0.f);
+  hipLaunchKernelGGL(row_stats_kernel, dim3(waves_blocks(G)), dim3(256), 0, st, gallery, stat_w, G, D, 1, 0.f);
+  GemmEpi ep = {};
+  ep.stat_a = stat_a; ep.stat_w = stat_w; ep.recs = recs;
+  int rc = launch_gemm<MODE_DIST>(emb, gallery, B, G, D, ep, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(match_finalize_rec_kernel, dim3(waves_blocks(B)), dim3(256), 0, st, emb, gallery, (const MatchRec*)recs, nslots, 32,
+                     idx_out, dist_out, id_or_unknown_out, packed_out, thresh, B, G, D);
   FRMAP_LAUNCH_CHECK();
   return 0;
 }
@@ -914,7 +971,7 @@ extern "C" int frmap_match_pack_gallery(const float* gallery, void* packed_out, 
   return 0;
 }
 
-// frmap_match_top1 for a prepared gallery (same outputs, same contract).  workspace: frmap_head_workspace_bytes(B, 0) + 16 B
+// frmap_match_top1 for a prepared gallery (same outputs, same contract).  workspace: frmap_match_workspace_bytes(B, G)
 // bytes; probe_split: B * 3 * D fp16 scratch.
 extern "C" int frmap_match_top1_packed(const float* emb, const float* gallery, const void* gallery_packed, const float* stat_w,
                                        int32_t* idx_out, float* dist_out, int32_t* id_or_unknown_out, int32_t* packed_out,
@@ -922,16 +979,22 @@ extern "C" int frmap_match_top1_packed(const float* emb, const float* gallery, c
   FRMAP_REQUIRE(emb && gallery && gallery_packed && stat_w && idx_out && dist_out && workspace && probe_split, "match_top1_packed: null pointer");
   FRMAP_REQUIRE(B > 0 && G > 0 && D > 0 && D % 32 == 0, "match_top1_packed: bad shape B=%d G=%d D=%d", B, G, D);
   hipStream_t st = (hipStream_t)stream;
-  unsigned long long* keys = (unsigned long long*)workspace;
-  float* stat_a = (float*)(keys + B + (B & 1));   // [B][4], 16-byte aligned
-  hipLaunchKernelGGL(fill_u64_kernel, dim3((B + 255) / 256), dim3(256), 0, st, keys, B, ~0ull);
+  // workspace: records [Gpad / 64][B] (Gpad = G rounded up to 256: the GEMM's padded rows write never-candidate records) | statistics [B][4]
+  const int nslots = (G + 255) / 256 * 4;
+  MatchRec* recs = (MatchRec*)workspace;
+  float* stat_a = (float*)(recs + (size_t)nslots * B);
   hipLaunchKernelGGL(match_row_prep_kernel, dim3(waves_blocks(B)), dim3(256), 0, st, emb, stat_a, (_Float16*)probe_split, B, D);
-  const int rc = frmap_match_gemm_f16x3(probe_split, gallery_packed, stat_a, stat_w, keys, B, G, D, st);
+  const int rc = frmap_match_gemm_f16x3(probe_split, gallery_packed, stat_a, stat_w, recs, B, G, D, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(match_finalize_kernel, dim3(waves_blocks(B)), dim3(256), 0, st, emb, gallery, keys, idx_out, dist_out,
-                     id_or_unknown_out, packed_out, thresh, B, G, D);
+  hipLaunchKernelGGL(match_finalize_rec_kernel, dim3(waves_blocks(B)), dim3(256), 0, st, emb, gallery, (const MatchRec*)recs, nslots, 64,
+                     idx_out, dist_out, id_or_unknown_out, packed_out, thresh, B, G, D);
   FRMAP_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" size_t frmap_match_workspace_bytes(int B, int G) {
+  const size_t b = B > 0 ? (size_t)B : 0, g = G > 0 ? (size_t)G : 0;
+  return 16 * b * (4 * ((g + 127) / 128)) + 16 * b + 8 * g + 256;
 }
 
 extern "C" int frmap_cosine_logits(const float* x, const float* w, float* logits_out, int32_t* argmax_out,

@@ -457,6 +457,11 @@ def _workspace(B: int, Cc: int, device) -> torch.Tensor:
     return torch.empty(((n + 15) // 16) * 2, dtype=torch.int64, device=device)
 
 
+def _match_workspace(B: int, G: int, device) -> torch.Tensor:
+    n = _lib.load().frmap_match_workspace_bytes(B, G)
+    return torch.empty(((n + 15) // 16) * 2, dtype=torch.int64, device=device)
+
+
 def _packed_buf(packed, B: int, device):
     """``packed``: False/None -> no record output; True -> a fresh int32 [B, 2]; a tensor -> written in place (a
     contiguous int32 [B, 2] view, e.g. one micro-batch's slice of the step's record buffer)."""
@@ -513,7 +518,9 @@ def match_top1(emb: torch.Tensor, gallery: torch.Tensor, thresh: Optional[float]
             raise ValueError("match_top1: `prepared` was built from a different (or since modified) gallery")
         idx = torch.empty((B,), dtype=torch.int32, device=emb.device)
         dist = torch.empty((B,), dtype=torch.float32, device=emb.device)
-        ws = _workspace(2 * B + 2, 0, emb.device)     # keys [B] + per-probe statistics [B][4]
+        if D != prepared.D:
+            raise ValueError(f"match_top1: embedding dim {D} != prepared gallery dim {prepared.D}")
+        ws = _match_workspace(B, G, emb.device)       # candidate records + per-probe statistics
         split = torch.empty((B, 3 * D), dtype=torch.float16, device=emb.device)
         ids = torch.empty((B,), dtype=torch.int32, device=emb.device) if thresh is not None else None
         pk = _packed_buf(packed, B, emb.device)
@@ -534,7 +541,7 @@ def match_top1(emb: torch.Tensor, gallery: torch.Tensor, thresh: Optional[float]
         gptr = gallery.data_ptr()
     idx = torch.empty((B,), dtype=torch.int32, device=emb.device)
     dist = torch.empty((B,), dtype=torch.float32, device=emb.device)
-    ws = _workspace(B, G, emb.device)
+    ws = _match_workspace(B, G, emb.device)
     ids = torch.empty((B,), dtype=torch.int32, device=emb.device) if thresh is not None else None
     pk = _packed_buf(packed, B, emb.device)
     _lib.check(_lib.load().frmap_match_top1(emb.data_ptr(), gptr, idx.data_ptr(), dist.data_ptr(),

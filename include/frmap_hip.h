@@ -273,7 +273,12 @@ int frmap_cnn_attention(const void* qkv, const void* x, const float* gamma, cons
  *                      dist +inf.  id_or_unknown_out (optional int32[B]) = idx if dist <= thresh else -1
  *                      (compare_faces' "Unknown", src/app.py:64).  packed_out (optional int32[B][2]) =
  *                      {id_or_unknown, bits of dist}: the 8-byte record the multi-GPU all-gather ships.
- *                      G <= 64 takes a one-launch exact path.
+ *                      G <= 64 takes a one-launch exact scan.  G > 64: a GEMM scores every pair by the
+ *                      expanded squared distance WITH a worst-case rounding bound, and every gallery row
+ *                      that could be the minimiser within that bound is re-scored with the exact
+ *                      ||(e - g) + 1e-6||_2 (float64 accumulation); the first row attaining the exact
+ *                      minimum wins.  The index is therefore the reference loop's, not the expanded
+ *                      form's (near-duplicate enrolments, un-normalised embeddings included).
  *   frmap_cosine_logits : logits[b][c] = s * <x_b/||x_b||, w_c/||w_c||>  and (optionally)
  *                      argmax_out[b] — class-centre match (src/hyperparameter_tuning.py:1038-1046,
  *                      src/face_models.py:889-893).  logits_out may be NULL.
@@ -289,20 +294,23 @@ int frmap_softmax_argmax(const float* logits, float* probs_out, int32_t* pred_ou
 int frmap_pairwise_distance(const float* a, const float* b, float* dist_out, int32_t* same_out, float thresh,
                             int B, int D, void* stream);
 
-/* Scratch each of the three calls below needs (device, caller-owned, >= this many bytes, 16-byte
- * aligned); C = G for frmap_match_top1. */
+/* Scratch frmap_cosine_logits / frmap_arcmargin_eval need (device, caller-owned, >= this many bytes, 16-byte
+ * aligned). */
 size_t frmap_head_workspace_bytes(int B, int C);
+/* Scratch of frmap_match_top1 and frmap_match_top1_packed for B probes against G gallery rows (candidate records +
+ * row statistics; device, caller-owned, 16-byte aligned). */
+size_t frmap_match_workspace_bytes(int B, int G);
 int frmap_match_top1(const float* emb, const float* gallery, int32_t* idx_out, float* dist_out,
                      int32_t* id_or_unknown_out, int32_t* packed_out, float thresh, void* workspace,
                      int B, int G, int D, void* stream);
-/* The same match for LARGE galleries on the fp16 MFMA pipe (same outputs, same contract: first minimum of the
- * expanded squared distance, exact F.pairwise_distance of the winner).  Every fp32 operand is split into two fp16
+/* The same match for LARGE galleries on the fp16 MFMA pipe (same outputs, same contract, same exact re-scoring of
+ * every in-band candidate).  Every fp32 operand is split into two fp16
  * numbers (hi = fp16(S x), lo = fp16(S x - hi)); one K = 3 D GEMM accumulates a_hi.g_hi + a_hi.g_lo + a_lo.g_hi in
  * fp32 (the fp32 dot product to ~2^-22).  frmap_match_pack_gallery prepares a gallery ONCE: packed_out
  * (frmap_match_gallery_pack_bytes(G, D) bytes) and stat_w_out [G][4]; D % 32 == 0.  Each row is scaled by its own power
  * of two before the split, so any finite magnitude is safe.  frmap_match_top1_packed: workspace =
- * frmap_head_workspace_bytes(2 * B + 2, 0) bytes, probe_split = B * 3 * D fp16 of scratch; `gallery` is still the fp32 matrix
- * (the winner's exact distance is recomputed from it). */
+ * frmap_match_workspace_bytes(B, G) bytes, probe_split = B * 3 * D fp16 of scratch; `gallery` is still the fp32 matrix
+ * (candidates are re-scored from it). */
 size_t frmap_match_gallery_pack_bytes(int G, int D);
 int frmap_match_pack_gallery(const float* gallery, void* packed_out, float* stat_w_out, int G, int D, void* stream);
 int frmap_match_top1_packed(const float* emb, const float* gallery, const void* gallery_packed, const float* stat_w,

@@ -18,5 +18,7 @@ for B, C in ((1024, 1000), (1024, 10000), (256, 36)):
     a = t(lambda: ops.arcmargin_eval(x, w, lab, 30.0, 0.5))
     c = t(lambda: ops.cosine_logits(x, w, 1.0, want_logits=False))
     m = t(lambda: ops.match_top1(e, g))
+    prep = ops.match_prepare(g) if C >= ops.MATCH_MFMA_MIN_G else None
+    mp = t(lambda: ops.match_top1(e, g, prepared=prep)) if prep is not None else float("nan")
     fl = 2.0 * B * C * 512
-    print(f"B={B} C={C}: arcmargin_eval {a:7.1f} us ({fl/a/1e6:6.1f} TF)  cosine top-1 {c:7.1f} us  match_top1 {m:7.1f} us ({fl/m/1e6:6.1f} TF)", flush=True)
+    print(f"B={B} C={C}: arcmargin_eval {a:7.1f} us ({fl/a/1e6:6.1f} TF)  cosine top-1 {c:7.1f} us  match_top1 {m:7.1f} us ({fl/m/1e6:6.1f} TF)  packed (fp16x3 MFMA) {mp:7.1f} us", flush=True)
