@@ -54,6 +54,21 @@ HBM_PEAK_GBS = 8000.0       # HBM3E spec, MI355X_MICROARCH.md (≈6.3 TB/s achie
 TRAFFIC_PROFILE = "r02_hbm_traffic_pmc.json"
 
 
+def step_stats(ms):
+    """Spread of the per-step durations (HIP events recorded between the steps of the timed region)."""
+    v = sorted(float(t) for t in ms)
+    if not v:
+        return None
+
+    def q(f):
+        i = f * (len(v) - 1)
+        lo = int(i)
+        hi = min(lo + 1, len(v) - 1)
+        return v[lo] + (v[hi] - v[lo]) * (i - lo)
+    return {"n": len(v), "median": round(q(0.5), 4), "p10": round(q(0.1), 4), "p90": round(q(0.9), 4),
+            "min": round(v[0], 4), "max": round(v[-1], 4)}
+
+
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -388,7 +403,7 @@ def worker(args) -> int:
     need_norm = model_type in ("cnn", "baseline", "hybrid", "attention")
     total = B * world
 
-    def make_local_step(mdl, xin, use_graph, nstreams):
+    def make_local_step(mdl, xin, use_graph, nstreams, gallery=gallery, need_norm=need_norm):
         graphed, note = None, ""
         if use_graph:
             try:
@@ -469,8 +484,11 @@ def worker(args) -> int:
             if int(flag.item()) == 0:
                 overlap = False  # (every rank takes the same decision)
 
-    def timed_region(step_fn, settle, warmup, steps, collective):
-        """settle + warmup untimed steps, then EXACTLY `steps` steps bracketed by barrier + synchronize on both sides."""
+    def timed_region(step_fn, settle, warmup, steps, collective, per_step=None):
+        """settle + warmup untimed steps, then EXACTLY `steps` steps bracketed by barrier + synchronize on both sides.
+        `per_step` (a list): receives the duration of every timed step in ms, from HIP events recorded on the launch stream
+        between the steps (an event record is a host-side enqueue; nothing waits inside the region)."""
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if per_step is not None else None
         with torch.no_grad():
             for _ in range(max(settle, 0)):      # a fixed COUNT: every rank must issue the same number of collectives
                 step_fn()
@@ -481,20 +499,65 @@ def worker(args) -> int:
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(steps):
+            if evs:
+                evs[0].record()
+            for i in range(steps):
                 step_fn()
+                if evs:
+                    evs[i + 1].record()
             torch.cuda.synchronize()
             if collective:
                 dist.barrier()
-            return time.perf_counter() - t0
+            el = time.perf_counter() - t0
+        if evs:
+            per_step.extend(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+        return el
 
-    local_elapsed = timed_region(step, args.settle_steps, args.warmup, args.steps, world > 1)
+    # N > 1: before anything is timed, every rank runs the SAME faces (one seed) through the same step and the gathered
+    # records must hold `world` bit-identical segments: a rank's result does not depend on which GPU computed it.  (Holds
+    # because every rank runs the same per-rank batch size, hence the same tile layouts and fp32 summation order; results
+    # of DIFFERENT batch sizes agree only to rounding, tests/test_properties_gpu.py.)
+    shard_check = None
+    if world > 1:
+        gen_s = torch.Generator(device=dev)
+        gen_s.manual_seed(seeds[1] + 4242)
+        if args.input == "u8":
+            x_same = torch.randint(0, 256, (B, 224, 224, 3), device=dev, dtype=torch.uint8, generator=gen_s)
+        else:
+            x_same = torch.randn((B, 3, 224, 224), device=dev, dtype=torch.float32, generator=gen_s)
+        with torch.no_grad():
+            rec_same = frmap_amd.embed_and_match(model, x_same, gallery, 1.0, normalize=need_norm, packed=True)
+            ids_all, d_all = fdist.gather_packed(rec_same)
+            torch.cuda.synchronize()
+        ok = fdist.replicated_shards_identical(ids_all, d_all, world) and \
+            bool(torch.equal(ids_all[:B].to(rec_same.device), rec_same[:, 0]))
+        flag = torch.tensor([1 if ok else 0], device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            raise SystemExit(f"bench.py rank {rank}: identical inputs gave different top-1 records on different ranks")
+        shard_check = {"identical_inputs_on_all_ranks": "bit-identical (id, distance) records from every rank",
+                       "faces": B, "condition": "equal per-rank batch size (same tile layouts / fp32 summation order)"}
+        del x_same, rec_same
+
+    per_step_ms = []
+    local_elapsed = timed_region(step, args.settle_steps, args.warmup, args.steps, world > 1, per_step_ms)
     elapsed_t = torch.tensor([local_elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(elapsed_t, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed_t.item())
     faces_per_s = total * args.steps / elapsed
     dt = "BF16" if dtype == torch.bfloat16 else "F16"
+
+    # N > 1: the same per-GPU step WITHOUT the collective, all ranks at once (same power / thermal conditions as the
+    # timed region): value / (N * local_only) isolates what the all-gather and rank skew cost
+    local_only = None
+    if world > 1:
+        t_loc = timed_region(lambda: local_records(), 20, args.warmup, args.steps, True)
+        v = torch.tensor([B * args.steps / t_loc], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        vmin = v.clone()
+        dist.all_reduce(vmin, op=dist.ReduceOp.MIN)
+        local_only = {"per_gpu_value_rank0": round(float(v.item()), 1), "per_gpu_value_slowest_rank": round(float(vmin.item()), 1),
+                      "what": "the same step without the all-gather, every rank at once, faces/s per GPU"}
 
     # ---------------- roofline: per-kernel instrumented pass (not part of `value`) ----------------
     roofline = None
@@ -574,6 +637,33 @@ def worker(args) -> int:
             extras["extras_error"] = f"{type(e).__name__}: {e}"
         torch.cuda.synchronize()
 
+    # ---------------- scale_ref: the multi-GPU workload's per-GPU shape on ONE GPU (N = 1 only) ----------------
+    # `--gpus N > 1` measures configs[3] (arcface, 1024 faces per GPU, 10 000 IDs); this line's `value` is configs[1].  A
+    # scaling curve must divide like by like: value(N) / (N * scale_ref.value).
+    scale_ref = None
+    if (rank == 0 and world == 1 and not args.no_extras and args.model is None and args.batch is None and args.gallery is None
+            and args.input == "f32"):
+        try:
+            m4 = frmap_amd.get_model("arcface", 36)
+            m4.load_state_dict(synth.calibrated_state_dict("arcface", synth.shapes_of(m4), 1004))
+            m4 = m4.to(dev).eval().set_compute_dtype(dtype)
+            g4 = frmap_amd.Gallery([f"id{i}" for i in range(10000)], synth.unit_rows(3004, 10000, 512), dev)
+            gen4 = torch.Generator(device=dev)
+            gen4.manual_seed(2004)
+            x4 = torch.randn((1024, 3, 224, 224), device=dev, dtype=torch.float32, generator=gen4)
+            rec4, _, _ = make_local_step(m4, x4, bool(args.graph), args.streams, gallery=g4, need_norm=False)
+            ms4 = []
+            t4 = timed_region(rec4, 30, args.warmup, args.steps, False, ms4)
+            scale_ref = {"value": round(1024 * args.steps / t4, 1), "unit": "faces/s", "ms_per_step": round(t4 / args.steps * 1e3, 4),
+                         "step_ms": step_stats(ms4),
+                         "workload": "BASELINE.json configs[3] per-GPU shape on one GPU: ResNet18-ArcFace embed + top-1 match, 1024 faces, "
+                                     "10 000-ID gallery, no collective",
+                         "use": "denominator of the scaling curve: efficiency(N) = value(N) / (N * scale_ref.value)"}
+            del m4, g4, x4, rec4
+        except Exception as e:
+            scale_ref = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.synchronize()
+
     # ---------------- CPU baseline: the oracle on the host cores (bounded sample) -----------------
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -614,7 +704,8 @@ def worker(args) -> int:
         line = {
             "metric": "faces/sec (224x224 embed+match)", "value": round(faces_per_s, 1), "unit": "faces/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": max(args.settle_steps, 0),
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "step_ms": step_stats(per_step_ms),
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{names.get(model_type, model_type)} embed + L2-normalise + top-1 match, batch {B}/GPU, "
                                    f"{G}-ID gallery, 224x224x3 " + ("fp32 NCHW" if args.input == "f32" else "uint8 HWC") + " inputs resident in HBM, seeded random-init weights "
@@ -626,6 +717,12 @@ def worker(args) -> int:
                                      else f"eager launches, {args.streams} stream(s)" + graph_note)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
+        if scale_ref is not None:
+            line["scale_ref"] = scale_ref
+        if shard_check is not None:
+            line["shard_check"] = shard_check
+        if local_only is not None:
+            line["local_only"] = local_only
         line.update(extras)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -82,6 +82,22 @@ def gather_packed(records: torch.Tensor, group: Optional[dist.ProcessGroup] = No
     return recv[:, 0], recv.view(torch.float32)[:, 1]
 
 
+def replicated_shards_identical(ids: torch.Tensor, dists: torch.Tensor, world: int) -> bool:
+    """True iff a gathered result (``world`` equal segments, in rank order) holds the SAME records in every segment -
+    what the all-gather returns when every rank was given identical faces.  Distances are compared by their bits."""
+    n = ids.shape[0]
+    if world <= 0 or n % world:
+        return False
+    per = n // world
+    i0, d0 = ids[:per], dists[:per].contiguous().view(torch.int32)
+    for r in range(1, world):
+        if not torch.equal(ids[r * per:(r + 1) * per], i0):
+            return False
+        if not torch.equal(dists[r * per:(r + 1) * per].contiguous().view(torch.int32), d0):
+            return False
+    return True
+
+
 def sharded_embed_and_match(match_fn: Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]],
                             x_global_or_shard: torch.Tensor, total: int, already_sharded: bool = False,
                             group: Optional[dist.ProcessGroup] = None) -> Tuple[torch.Tensor, torch.Tensor]:

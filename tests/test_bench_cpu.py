@@ -75,6 +75,16 @@ def test_launcher_parent_never_imports_torch():
     assert "SPAWN 2 ['--gpus', '2', '--steps', '3'] False" in r.stdout
 
 
+def test_step_statistics_and_scaling_reference_are_reported():
+    st = bench.step_stats([1.0, 1.1, 1.2, 5.0, 1.05])
+    assert st == {"n": 5, "median": 1.1, "p10": 1.02, "p90": 3.48, "min": 1.0, "max": 5.0} and bench.step_stats([]) is None
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    # the N = 1 line carries the multi-GPU workload's per-GPU shape as the scaling denominator, every line its per-step spread,
+    # and the N > 1 path refuses to time anything unless identical inputs give bit-identical records on every rank
+    assert 'line["scale_ref"] = scale_ref' in src and '"step_ms": step_stats(per_step_ms)' in src
+    assert "fdist.replicated_shards_identical(ids_all, d_all, world)" in src and 'line["shard_check"] = shard_check' in src
+
+
 def test_default_workloads_follow_baseline_configs():
     a = bench.parse([])
     assert a.gpus == 1 and a.model is None and a.batch is None and a.gallery is None   # resolved per world size in worker()

@@ -35,6 +35,11 @@ def _worker(rank, world, port, total, q):
             rec = torch.stack([mi, md.view(torch.int32)], dim=1)
             i3, d3 = fdist.gather_packed(rec)
             same = same and i3.tolist() == ids.tolist() and d3.tolist() == d.tolist()
+            # bench.py's N > 1 self-check: identical faces on every rank -> `world` bit-identical segments; rank-specific
+            # faces (the shards above) are not
+            mi, md = _fake_match(x[:total // world])
+            i4, d4 = fdist.gather_packed(torch.stack([mi, md.view(torch.int32)], dim=1))
+            same = same and fdist.replicated_shards_identical(i4, d4, world) and not fdist.replicated_shards_identical(i3, d3, world)
         q.put((rank, ids.tolist(), d.tolist(), same))
     finally:
         dist.destroy_process_group()
