@@ -13,7 +13,7 @@ import threading
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libfrmap_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _lock = threading.Lock()
 _lib = None
@@ -73,6 +73,19 @@ PROTOTYPES = {
     "frmap_gap_norm_match": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _f, _i, _i, _i, _i, _i, _vp]),
     "frmap_cosine_logits": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "frmap_arcmargin_eval": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
+    # model handles
+    "frmap_model_create": (_i, [C.POINTER(_vp), C.c_char_p, _i, _i]),
+    "frmap_model_load_tensor": (_i, [_vp, C.c_char_p, _vp, _sz, _i]),
+    "frmap_model_set_input_normalization": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "frmap_model_finalize": (_i, [_vp, _vp]),
+    "frmap_model_embedding_dim": (_i, [_vp]),
+    "frmap_model_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
+    "frmap_model_match_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "frmap_model_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "frmap_model_embed_and_match": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "frmap_model_trace": (_i, [_vp, _i]),
+    "frmap_model_trace_read": (_i, [_vp, _vp, _i]),
+    "frmap_model_destroy": (None, [_vp]),
 }
 
 

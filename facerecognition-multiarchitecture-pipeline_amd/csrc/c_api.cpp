@@ -42,5 +42,5 @@ int frmap_big_lds(const void* kern, int bytes) {
   return 0;
 }
 
-extern "C" int frmap_abi_version(void) { return 7; }
+extern "C" int frmap_abi_version(void) { return 8; }
 extern "C" const char* frmap_last_error(void) { return g_err; }

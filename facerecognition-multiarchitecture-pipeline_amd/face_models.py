@@ -52,6 +52,7 @@ def _bn_scale_shift(bn: nn.Module, bias: Optional[torch.Tensor] = None) -> Tuple
     return scale.contiguous(), shift.contiguous()
 
 
+_PY_PLAN = os.environ.get("FRMAP_PY_PLAN", "0") == "1"      # A/B switch: 1 = plan the ResNet-18 families in Python (per-op C ABI calls)
 _HEAD_FUSE = os.environ.get("FRMAP_HEAD_FUSE", "1") != "0"   # A/B switch: 0 = ArcFace head as avgpool + linear + normalize launches
 _POOL_FUSE = os.environ.get("FRMAP_POOL_FUSE", "1") != "0"   # A/B switch: 0 = conv and 2x2 max-pool as two launches
 
@@ -225,7 +226,33 @@ class ResNet18(nn.Module):
 
 
 class _TrunkPlan:
-    """Packed ResNet-18 trunk: stem conv → maxpool → 8 BasicBlocks (→ global average pool)."""
+    """ResNet-18 trunk (and, for 'cnn' / 'arcface', the heads) on a MODEL HANDLE of the C ABI (`frmap_model_*`,
+    csrc/model_api.cpp): BatchNorm folding, weight packing and the per-layer kernel plan live in the library; this class only
+    hands over the tensors under the reference's ``state_dict`` key names and asks for outputs."""
+
+    def __init__(self, model_type: str, state: Dict[str, torch.Tensor], num_classes: int, dtype: torch.dtype,
+                 mean=IMAGENET_MEAN, std=IMAGENET_STD):
+        self.dtype = dtype
+        self.handle = ops.ModelHandle(model_type, state, num_classes, dtype, mean, std)
+
+    def features(self, x: torch.Tensor) -> torch.Tensor:
+        """fp32 NCHW (or uint8 HWC) → NHWC B×7×7×512 (for 224² input) in the compute dtype."""
+        return self.handle.forward(x, ops.OUT_TRUNK_MAP)
+
+    def pooled(self, x: torch.Tensor) -> torch.Tensor:
+        return self.handle.forward(x, ops.OUT_POOLED)  # fp32 B×512
+
+
+def _trunk_plan(rn: "ResNet18", dtype: torch.dtype, mean, std):
+    """The bare trunk of HybridNet / AttentionNet: a 'resnet18_trunk' handle, or the Python planner under FRMAP_PY_PLAN=1."""
+    if _PY_PLAN:
+        return _PyTrunkPlan(rn, dtype, mean, std)
+    return _TrunkPlan("resnet18_trunk", dict(rn.state_dict()), 0, dtype, mean, std)
+
+
+class _PyTrunkPlan:
+    """The same trunk planned in Python, one C-ABI op per call (`FRMAP_PY_PLAN=1`): the A/B twin of the model handle - same
+    launches on the same folded weights, bit-identical outputs (tests/test_model_cabi_gpu.py) - and the path per-op tools wrap."""
 
     def __init__(self, rn: ResNet18, dtype: torch.dtype, mean=IMAGENET_MEAN, std=IMAGENET_STD):
         self.dtype = dtype
@@ -347,13 +374,24 @@ class ResNetTransfer(_HipModule):
             param.requires_grad = True
 
     def _build_plan(self, dtype):
-        return _TrunkPlan(self.resnet, dtype, self.input_mean, self.input_std)
+        if _PY_PLAN:
+            return _PyTrunkPlan(self.resnet, dtype, self.input_mean, self.input_std)
+        fc = self.resnet.fc[1]
+        return _TrunkPlan("cnn", {f"resnet.{k}": v for k, v in self.resnet.state_dict().items()}, fc.out_features, dtype,
+                          self.input_mean, self.input_std)
+
+    def model_handle(self):
+        """The `frmap_model` behind this module (None under FRMAP_PY_PLAN=1): `matching.embed_and_match` runs on it in one call."""
+        p = self._get_plan()
+        return p.handle if isinstance(p, _TrunkPlan) else None
 
     def forward(self, x):
         x = self._check_input(x)
-        f = self._get_plan().pooled(x)
+        p = self._get_plan()
+        if isinstance(p, _TrunkPlan):
+            return p.handle.forward(x, ops.OUT_LOGITS)
         fc = self.resnet.fc[1]
-        return ops.linear_f32(f, fc.weight.detach(), None, fc.bias.detach())
+        return ops.linear_f32(p.pooled(x), fc.weight.detach(), None, fc.bias.detach())
 
     def trunk_map(self, x):
         """The NHWC trunk output whose global average pool is ``get_embedding`` (`face_models.py:98-102`); lets
@@ -533,8 +571,21 @@ class ArcFaceNet(_HipModule):
 
     def _build_plan(self, dtype):
         scale, shift = _bn_scale_shift(self.bn)
-        return {"trunk": _TrunkPlan(self.backbone, dtype, self.input_mean, self.input_std), "bn_scale": scale, "bn_shift": shift,
+        if _PY_PLAN or not _HEAD_FUSE:
+            trunk = _PyTrunkPlan(self.backbone, dtype, self.input_mean, self.input_std) if _PY_PLAN else \
+                _trunk_plan(self.backbone, dtype, self.input_mean, self.input_std)
+        else:
+            state = {f"backbone.{k}": v for k, v in self.backbone.state_dict().items()}
+            state.update({"embedding.weight": self.embedding.weight, "val_classifier.weight": self.val_classifier.weight,
+                          "val_classifier.bias": self.val_classifier.bias})
+            state.update({f"bn.{k}": v for k, v in self.bn.state_dict().items()})
+            trunk = _TrunkPlan("arcface", state, self.val_classifier.out_features, dtype, self.input_mean, self.input_std)
+        return {"trunk": trunk, "bn_scale": scale, "bn_shift": shift,
                 "wt": self.embedding.weight.detach().float().t().contiguous()}   # [K][N] for the fused head
+
+    def model_handle(self):
+        t = self._get_plan()["trunk"]
+        return t.handle if isinstance(t, _TrunkPlan) and t.handle.model_type == "arcface" else None
 
     def _pre_norm(self, x):
         p = self._get_plan()
@@ -544,6 +595,10 @@ class ArcFaceNet(_HipModule):
     def get_embedding(self, x):
         x = self._check_input(x)
         p = self._get_plan()
+        h = self.model_handle()
+        if h is not None:
+            # avgpool + embedding + bn + F.normalize (`face_models.py:584-590`): the handle's head, one launch after the trunk
+            return h.forward(x, ops.OUT_EMBEDDING)
         if _HEAD_FUSE and p["wt"].shape[1] in (256, 512):
             # avgpool + embedding + bn + F.normalize (`face_models.py:584-590`) in one launch
             return ops.gap_linear_norm(p["trunk"].features(x), p["wt"], p["bn_scale"], p["bn_shift"], 1e-12)[0]
@@ -558,6 +613,8 @@ class ArcFaceNet(_HipModule):
         # `face_models.py:576`: the classifier rows are re-normalised in place on every eval call
         if self.val_classifier.weight.is_cuda:
             self.val_classifier.weight.data.copy_(ops.l2_normalize(self.val_classifier.weight.data, 1e-12))
+            if self._plan is not None:
+                self._plan_sig = self._signature()   # the plan does not depend on the classifier rows: no rebuild for this write
         if labels is not None:
             return ops.linear_f32(emb, self.val_classifier.weight.detach(), None, self.val_classifier.bias.detach())
         return emb
@@ -614,7 +671,7 @@ class HybridNet(_HipModule):
         tr = self.transformer
         f32 = lambda t: t.detach().float().contiguous()
         return {
-            "trunk": _TrunkPlan(self.cnn, dtype, self.input_mean, self.input_std),
+            "trunk": _trunk_plan(self.cnn, dtype, self.input_mean, self.input_std),
             "pos": f32(self.pos_encoding).view(self.seq_len, self.fdim),
             "n1": (f32(tr.norm1.weight), f32(tr.norm1.bias)), "n2": (f32(tr.norm2.weight), f32(tr.norm2.bias)),
             "nf": (f32(self.norm.weight), f32(self.norm.bias)),
@@ -697,7 +754,7 @@ class AttentionNet(_HipModule):
         a = self.attention
         w = torch.cat([a.query.weight, a.key.weight, a.value.weight], dim=0).detach().float()
         bias = torch.cat([a.query.bias, a.key.bias, a.value.bias], dim=0).detach().float()
-        return {"trunk": _TrunkPlan(self.backbone, dtype, self.input_mean, self.input_std), "qkv": ops.pack_conv_weight(w.contiguous(), dtype),
+        return {"trunk": _trunk_plan(self.backbone, dtype, self.input_mean, self.input_std), "qkv": ops.pack_conv_weight(w.contiguous(), dtype),
                 "qkv_bias": bias.contiguous(), "cq": a.query.weight.shape[0], "cqkv": w.shape[0],
                 "gamma": a.gamma.detach().float().contiguous(),
                 "sw": a.spatial_attention.conv.weight.detach().float().contiguous(),

@@ -149,6 +149,12 @@ def embed_and_match(model, x: torch.Tensor, gallery, thresh: float = REC_THRESH,
     record tensor ``(id, bits(dist))`` the multi-GPU all-gather ships (``dist.gather_packed``); ``packed=<tensor>``
     writes those records into the given int32 ``[B, 2]`` buffer (a slice of a larger step buffer)."""
     g = _as_gallery(gallery, x.device if isinstance(x, torch.Tensor) and x.is_cuda else "cuda")
+    h = model.model_handle() if hasattr(model, "model_handle") else None
+    if h is not None:
+        # 'cnn' / 'arcface': forward + match as ONE call on the model handle (`frmap_model_embed_and_match`)
+        _idx, dist, ids, pk, _ = h.embed_and_match(model._check_input(x), g.matrix if len(g) else None, g.prepared if len(g) else None,
+                                                   thresh, normalize, packed=packed)
+        return pk if (packed is not None and packed is not False) else (ids, dist)
     fmap = model.trunk_map(x) if hasattr(model, "trunk_map") and len(g) <= 64 else None
     if fmap is not None:
         # embedding == global average pool of the trunk map (ResNetTransfer): pool + normalise + match in one launch

@@ -641,3 +641,115 @@ for _name in ("pack_input", "pack_conv_weight", "pack_conv_weight_c3", "conv_sma
               "arcmargin_eval", "conv_small_cin_pool2", "conv_igemm_pool2", "gap_linear_norm"):
     globals()[_name] = _on_operand_device(globals()[_name])
 del _name
+
+
+# ------------------------------------------------------------------------------------------------
+# model handles (`frmap_model_*`): the per-layer plan, BatchNorm folding and weight packing live in the library
+# ------------------------------------------------------------------------------------------------
+IN_F32_NCHW, IN_U8_HWC = 0, 1
+OUT_TRUNK_MAP, OUT_POOLED, OUT_EMBEDDING, OUT_LOGITS = 0, 1, 2, 3
+
+
+class ModelHandle:
+    """A `frmap_model` built from a module's ``state_dict`` (the reference's key names, device tensors).  Immutable after
+    construction; forwards allocate only their outputs and scratch (torch's caching allocator, capturable into a HIP graph)."""
+
+    def __init__(self, model_type: str, state: dict, num_classes: int, dtype: torch.dtype, mean=None, std=None):
+        import ctypes as C
+        lib = _lib.load()
+        self._lib, self._h = lib, C.c_void_p()
+        self.dtype, self.model_type, self.num_classes = dtype, model_type, int(num_classes)
+        _lib.check(lib.frmap_model_create(C.byref(self._h), model_type.encode(), int(num_classes), dt_code(dtype)), "model_create")
+        try:
+            dev = None
+            for key, t in state.items():
+                if not (isinstance(t, torch.Tensor) and t.is_floating_point()):
+                    continue
+                if not t.is_cuda:
+                    raise RuntimeError(f"{key} is on {t.device}; move the module to the GPU (no CPU fallback)")
+                dev = t.device if dev is None else dev
+                tt = t.detach().to(torch.float32).contiguous()
+                with torch.cuda.device(tt.device):
+                    # (1 = a key the inference path does not use, e.g. the trunk's own 1000-way fc: ignored)
+                    _lib.check(min(lib.frmap_model_load_tensor(self._h, key.encode(), tt.data_ptr(), tt.numel(), 1), 0), f"model_load_tensor({key})")
+            self.device = dev
+            if mean is not None:
+                m3, s3 = (C.c_float * 3)(*[float(v) for v in mean]), (C.c_float * 3)(*[float(v) for v in std])
+                _lib.check(lib.frmap_model_set_input_normalization(self._h, m3, s3), "model_set_input_normalization")
+            with torch.cuda.device(dev):
+                _lib.check(lib.frmap_model_finalize(self._h, _stream()), "model_finalize")
+        except Exception:
+            lib.frmap_model_destroy(self._h)
+            self._h = None
+            raise
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.frmap_model_destroy(h)
+
+    @staticmethod
+    def _geometry(x):
+        if x.dtype == torch.uint8:
+            return IN_U8_HWC, x.shape[0], x.shape[1], x.shape[2]
+        return IN_F32_NCHW, x.shape[0], x.shape[2], x.shape[3]
+
+    def forward(self, x: torch.Tensor, what: int) -> torch.Tensor:
+        x = _dev(x, "model_forward.x")
+        kind, B, H, W = self._geometry(x)
+        with torch.cuda.device(x.device):
+            if what == OUT_TRUNK_MAP:
+                hq, wq = stem_pool_dims(H, W)
+                for _ in range(3):
+                    hq, wq = (hq - 1) // 2 + 1, (wq - 1) // 2 + 1
+                out = torch.empty((B, hq, wq, 512), dtype=self.dtype, device=x.device)
+            else:
+                out = torch.empty((B, self.num_classes if what == OUT_LOGITS else 512), dtype=torch.float32, device=x.device)
+            ws = torch.empty((self._lib.frmap_model_workspace_bytes(self._h, B, H, W),), dtype=torch.uint8, device=x.device)
+            _lib.check(self._lib.frmap_model_forward(self._h, x.data_ptr(), kind, B, H, W, what, out.data_ptr(), ws.data_ptr(), _stream()),
+                       "model_forward")
+        return out
+
+    def embed_and_match(self, x: torch.Tensor, gallery: Optional[torch.Tensor], prepared, thresh: float, normalize: bool,
+                        packed=False, want_emb: bool = False):
+        """One C call: forward + top-1 match.  Returns (idx, dist, ids, packed | None, emb | None)."""
+        x = _dev(x, "model_embed_and_match.x")
+        kind, B, H, W = self._geometry(x)
+        G = int(gallery.shape[0]) if gallery is not None else 0
+        with torch.cuda.device(x.device):
+            gptr = ppk = pst = 0
+            if G:
+                gallery = _dev(gallery, "model_embed_and_match.gallery", torch.float32)
+                if gallery.shape[1] != 512:
+                    raise ValueError(f"embed_and_match: embedding dim 512 != gallery dim {gallery.shape[1]}")
+                gptr = gallery.data_ptr()
+                if prepared is not None and G >= MATCH_MFMA_MIN_G:
+                    if not prepared.matches(gallery):
+                        raise ValueError("embed_and_match: `prepared` was built from a different (or since modified) gallery")
+                    ppk, pst = prepared.packed.data_ptr(), prepared.stat_w.data_ptr()
+            idx = torch.empty((B,), dtype=torch.int32, device=x.device)
+            dist = torch.empty((B,), dtype=torch.float32, device=x.device)
+            ids = torch.empty((B,), dtype=torch.int32, device=x.device)
+            pk = _packed_buf(packed, B, x.device)
+            emb = torch.empty((B, 512), dtype=torch.float32, device=x.device) if want_emb else None
+            ws = torch.empty((self._lib.frmap_model_match_workspace_bytes(self._h, B, H, W, G),), dtype=torch.uint8, device=x.device)
+            _lib.check(self._lib.frmap_model_embed_and_match(self._h, x.data_ptr(), kind, B, H, W, gptr, ppk, pst, G, float(thresh),
+                                                             int(bool(normalize)), idx.data_ptr(), dist.data_ptr(), ids.data_ptr(),
+                                                             pk.data_ptr() if pk is not None else 0,
+                                                             emb.data_ptr() if emb is not None else 0, ws.data_ptr(), _stream()),
+                       "model_embed_and_match")
+        return idx, dist, ids, pk, emb
+
+    def trace(self, enable: bool) -> None:
+        _lib.check(self._lib.frmap_model_trace(self._h, int(bool(enable))), "model_trace")
+
+    def trace_read(self, max_records: int = 4096):
+        """[(kernel label, algorithmic FLOPs, algorithmic bytes, microseconds)] of the forwards since the last read."""
+        import ctypes as C
+
+        class Rec(C.Structure):
+            _fields_ = [("kernel", C.c_char * 64), ("flop", C.c_double), ("bytes", C.c_double), ("us", C.c_float)]
+        buf = (Rec * max_records)()
+        n = self._lib.frmap_model_trace_read(self._h, C.cast(buf, C.c_void_p), max_records)
+        _lib.check(min(n, 0), "model_trace_read")
+        return [(buf[i].kernel.decode(), buf[i].flop, buf[i].bytes, buf[i].us) for i in range(n)]

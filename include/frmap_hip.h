@@ -339,6 +339,72 @@ int frmap_arcmargin_eval(const float* x, const float* w, const int64_t* label, f
                          float* minmax_out, void* workspace, int B, int C, int D, float s, float m,
                          int easy_margin, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Model handles: what `model(images)` / `model.get_embedding(images)` run in the reference
+ * (src/testing.py:255-273, src/app.py:44) as ONE call, for the ResNet-18 families of get_model()
+ * (src/face_models.py:785-813): 'cnn' = ResNetTransfer (:62-102), 'arcface' = ArcFaceNet eval (:447-613),
+ * 'resnet18_trunk' = the bare trunk (features only; HybridNet / AttentionNet build on it, :269,658).
+ *
+ *   frmap_model_create       model_type as get_model() spells it; num_classes sizes the classifier head; `dtype` = compute type.
+ *                            An unknown type is rejected with the reference's message ("Invalid model type: ...", :813).
+ *   frmap_model_load_tensor  one call per entry of the reference checkpoint's state_dict, under the SAME key
+ *                            ("resnet.layer1.0.bn1.running_var", "backbone.conv1.weight" or its alias "features.0.weight",
+ *                            "embedding.weight", "bn.weight", "val_classifier.bias", ...): fp32 data, `numel` elements, host
+ *                            memory (on_device = 0) or device memory (1).  Returns 0 = taken, 1 = a key the inference path does
+ *                            not use (ignored: training head, num_batches_tracked), -1 = wrong size.
+ *   frmap_model_finalize     folds every eval-mode BatchNorm into its conv / linear (fp32), packs the weights into the kernels'
+ *                            layout, fixes the layer plan; fails naming the first missing tensor.  Synchronises `stream` once.
+ *                            After it the handle is immutable: any thread / stream may run forwards on it concurrently.
+ *   frmap_model_forward      x: FRMAP_INPUT_F32_NCHW = fp32 [B][3][H][W] (the reference's tensor) or FRMAP_INPUT_U8_HWC = uint8
+ *                            [B][H][W][3] (ToTensor + Normalize applied inside the stem, src/testing.py:99-104);
+ *                            `what` selects the output written to the caller-owned `out`:
+ *                              FRMAP_OUT_TRUNK_MAP  [B][h][w][512] in `dtype`  (children()[:-2], face_models.py:660)
+ *                              FRMAP_OUT_POOLED     fp32 [B][512]              (children()[:-1] flattened, :100,464)
+ *                              FRMAP_OUT_EMBEDDING  fp32 [B][512]: get_embedding() - 'cnn': the pooled features (:98-102);
+ *                                                   'arcface': F.normalize(bn(embedding(pooled))) (:584-590)
+ *                              FRMAP_OUT_LOGITS     fp32 [B][num_classes]: forward() - 'cnn': resnet.fc (:93-96); 'arcface':
+ *                                                   val_classifier over row-normalised weights (:576-580)
+ *                            workspace: frmap_model_workspace_bytes(m, B, H, W) bytes, 256-byte aligned, caller-owned.
+ *                            Nothing is allocated, freed or synchronised; all launches go to `stream`.
+ *   frmap_model_embed_and_match  forward + compare_faces for every face (src/app.py:44,50-64): embedding (L2-normalised first if
+ *                            `normalize`, for models whose embedding is not unit-norm) -> first arg-min of ||e - g + 1e-6||_2
+ *                            over the fp32 gallery [G][512] -> outputs as frmap_match_top1.  gallery_packed / gallery_stat
+ *                            (frmap_match_pack_gallery; may be NULL) put galleries of >= 512 rows on the MFMA pipe; 'cnn' with
+ *                            G <= 64 pools, normalises and matches in one launch.  emb_out: optional fp32 [B][512].
+ *                            workspace: frmap_model_match_workspace_bytes(m, B, H, W, G).
+ *   frmap_model_trace / _trace_read  per-launch HIP-event timing of subsequent forwards (kernel label, algorithmic FLOPs and
+ *                            bytes, microseconds) for roofline reports; read synchronises the recorded events and clears them.
+ * ------------------------------------------------------------------------------------------- */
+#define FRMAP_INPUT_F32_NCHW 0
+#define FRMAP_INPUT_U8_HWC 1
+#define FRMAP_OUT_TRUNK_MAP 0
+#define FRMAP_OUT_POOLED 1
+#define FRMAP_OUT_EMBEDDING 2
+#define FRMAP_OUT_LOGITS 3
+typedef struct frmap_model frmap_model;
+typedef struct frmap_trace_record {
+  char kernel[64];
+  double flop;
+  double bytes;
+  float us;
+} frmap_trace_record;
+int frmap_model_create(frmap_model** out, const char* model_type, int num_classes, int dtype);
+int frmap_model_load_tensor(frmap_model* m, const char* key, const void* data, size_t numel, int on_device);
+int frmap_model_set_input_normalization(frmap_model* m, const float* mean3_host, const float* std3_host);
+int frmap_model_finalize(frmap_model* m, void* stream);
+int frmap_model_embedding_dim(const frmap_model* m);
+size_t frmap_model_workspace_bytes(const frmap_model* m, int B, int H, int W);
+size_t frmap_model_match_workspace_bytes(const frmap_model* m, int B, int H, int W, int G);
+int frmap_model_forward(frmap_model* m, const void* x, int x_kind, int B, int H, int W, int what, void* out,
+                        void* workspace, void* stream);
+int frmap_model_embed_and_match(frmap_model* m, const void* x, int x_kind, int B, int H, int W, const float* gallery,
+                                const void* gallery_packed, const float* gallery_stat, int G, float thresh, int normalize,
+                                int32_t* idx_out, float* dist_out, int32_t* id_or_unknown_out, int32_t* packed_out,
+                                float* emb_out, void* workspace, void* stream);
+int frmap_model_trace(frmap_model* m, int enable);
+int frmap_model_trace_read(frmap_model* m, frmap_trace_record* out, int max_records);
+void frmap_model_destroy(frmap_model* m);
+
 #ifdef __cplusplus
 }
 #endif

@@ -377,7 +377,8 @@ def test_uint8_input_stem_is_bit_identical_to_normalize_then_fp32_path(dtype, ca
     g = np.random.Generator(np.random.PCG64(4242))
     sd = calibrated_sd("cnn")
     m = _model("cnn", sd, dtype)
-    plan = m._get_plan()
+    import frmap_amd.face_models as fm
+    plan = fm._PyTrunkPlan(m.resnet, dtype)          # the packed stem weights, for the kernel-level comparison below
     for (B, H, W), pool3 in (((3, 224, 224), True), ((2, 160, 160), True), ((2, 112, 96), True), ((2, 224, 224), False), ((1, 64, 72), False)):
         x8 = torch.from_numpy(g.integers(0, 256, (B, H, W, 3), dtype=np.uint8)).to(DEV)
         xf = ops.normalize_u8(x8, evaluate.IMAGENET_MEAN, evaluate.IMAGENET_STD)[0]
