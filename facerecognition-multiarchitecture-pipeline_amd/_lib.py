@@ -31,6 +31,7 @@ PROTOTYPES = {
     "frmap_conv_small_cin": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "frmap_match_gallery_pack_bytes": (_sz, [_i, _i]),
     "frmap_match_pack_gallery": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "frmap_match_pack_gallery_rows": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "frmap_match_top1_packed": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp]),
     "frmap_resize_bilinear_u8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "frmap_gap_linear_norm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i, _vp]),
@@ -45,6 +46,9 @@ PROTOTYPES = {
     "frmap_conv_igemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "frmap_conv_pp_tuning": (_i, [_i, _i, _i]),
     "frmap_conv_pp_ri": (_i, [_i]),
+    "frmap_conv_pp_pitch": (_i, [_i]),
+    "frmap_conv_pp_ds": (_i, [_i]),
+    "frmap_conv_pp_im": (_i, [_i]),
     "frmap_conv1x1_pp_layout": (_i, [_i, _i, _i, _i, _i, _i]),
     "frmap_conv3x3_pp_layout": (_i, [_i, _i, _i, _i, _i]),
     "frmap_conv3x3s2_pp_layout": (_i, [_i, _i, _i, _i, _i]),

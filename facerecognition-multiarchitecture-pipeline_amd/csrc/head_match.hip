@@ -934,11 +934,11 @@ __global__ void match_row_prep_kernel(const float* __restrict__ x, float* __rest
 }
 
 __global__ void match_pack_gallery_kernel(const float* __restrict__ gal, const float* __restrict__ stat4, _Float16* __restrict__ out,
-                                          size_t total, int G, int D) {
+                                          size_t e_lo, size_t e_hi, int G, int D) {
   const int nchunks = 3 * D / 32;
-  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t e = e_lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; e < total; e += stride) {   // element order of frmap_pack_conv_weight for a 1x1 layer: [row/64][k/32][row%64][slot][8]
+  for (; e < e_hi; e += stride) {   // element order of frmap_pack_conv_weight for a 1x1 layer: [row/64][k/32][row%64][slot][8]
     const int j = (int)(e & 7), slot = (int)((e >> 3) & 3), cl = (int)((e >> 5) & 63);
     const size_t rest = e >> 11;
     const int chunk = (int)(rest % nchunks), ntile = (int)(rest / nchunks);
@@ -957,18 +957,39 @@ extern "C" size_t frmap_match_gallery_pack_bytes(int G, int D) {
   return (size_t)((G + 255) / 256 * 256) * 3 * D * sizeof(_Float16);
 }
 
+// (re)pack gallery rows [row_lo, row_hi) of a gallery that now holds G rows: statistics of those rows + every 64-row tile they touch.
+static int match_pack_rows(const float* gallery, void* packed_out, float* stat_w_out, int row_lo, int row_hi, int G, int D, hipStream_t st) {
+  hipLaunchKernelGGL(match_row_prep_kernel, dim3(waves_blocks(row_hi - row_lo)), dim3(256), 0, st, gallery + (size_t)row_lo * D,
+                     stat_w_out + 4 * (size_t)row_lo, (_Float16*)nullptr, row_hi - row_lo, D);
+  const size_t per_tile = (size_t)(3 * D / 32) * 2048;
+  const size_t e_lo = (size_t)(row_lo / 64) * per_tile;
+  // through the end of the last tile's 256-row padding group, so that rows G .. Gpad - 1 are (re)written as zeros
+  const size_t t_hi = row_hi >= G ? (size_t)((G + 255) / 256 * 4) : (size_t)((row_hi + 63) / 64);
+  const size_t e_hi = t_hi * per_tile;
+  const size_t n = e_hi - e_lo;
+  const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+  hipLaunchKernelGGL(match_pack_gallery_kernel, dim3(blocks), dim3(256), 0, st, gallery, (const float*)stat_w_out,
+                     (_Float16*)packed_out, e_lo, e_hi, G, D);
+  FRMAP_LAUNCH_CHECK();
+  return 0;
+}
+
 // one-time preparation of a gallery for frmap_match_top1_packed: packed_out (frmap_match_gallery_pack_bytes), stat_w_out [G][4]
 extern "C" int frmap_match_pack_gallery(const float* gallery, void* packed_out, float* stat_w_out, int G, int D, void* stream) {
   FRMAP_REQUIRE(gallery && packed_out && stat_w_out, "match_pack_gallery: null pointer");
   FRMAP_REQUIRE(G > 0 && D > 0 && D % 32 == 0, "match_pack_gallery: bad shape G=%d D=%d (D %% 32 == 0)", G, D);
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(match_row_prep_kernel, dim3(waves_blocks(G)), dim3(256), 0, st, gallery, stat_w_out, (_Float16*)nullptr, G, D);
-  const size_t total = (size_t)((G + 255) / 256 * 256) * 3 * D;
-  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(match_pack_gallery_kernel, dim3(blocks), dim3(256), 0, st, gallery, (const float*)stat_w_out,
-                     (_Float16*)packed_out, total, G, D);
-  FRMAP_LAUNCH_CHECK();
-  return 0;
+  return match_pack_rows(gallery, packed_out, stat_w_out, 0, G, G, D, (hipStream_t)stream);
+}
+
+// incremental enrolment (/root/reference/src/app.py:428-436 appends one identity): rows [row_lo, row_hi) of the gallery were
+// written (appended: row_hi == G, the new row count; or edited in place); only their statistics and 64-row tiles are re-packed.
+// packed_out / stat_w_out must have been sized for at least G rows (frmap_match_gallery_pack_bytes(capacity, D), [capacity][4]).
+extern "C" int frmap_match_pack_gallery_rows(const float* gallery, void* packed_out, float* stat_w_out, int row_lo, int row_hi,
+                                             int G, int D, void* stream) {
+  FRMAP_REQUIRE(gallery && packed_out && stat_w_out, "match_pack_gallery_rows: null pointer");
+  FRMAP_REQUIRE(G > 0 && D > 0 && D % 32 == 0 && row_lo >= 0 && row_lo < row_hi && row_hi <= G,
+                "match_pack_gallery_rows: bad range [%d, %d) of G=%d D=%d", row_lo, row_hi, G, D);
+  return match_pack_rows(gallery, packed_out, stat_w_out, row_lo, row_hi, G, D, (hipStream_t)stream);
 }
 
 // frmap_match_top1 for a prepared gallery (same outputs, same contract).  workspace: frmap_match_workspace_bytes(B, G)

@@ -2,8 +2,10 @@
 
 * input pipeline — ``transforms.Resize((224,224)) → ToTensor → Normalize(ImageNet)`` of
   `/root/reference/src/testing.py:99-104` (and the 160×160 / 0.5-0.5 variant of `src/app.py:39-42`):
-  the resize stays on the host (PIL bilinear, exactly what torchvision's PIL backend calls), the
-  uint8 → normalised-float step is ``ops.normalize_u8`` (3 bytes per pixel cross PCIe instead of 12);
+  the resize runs on the device (``resize.resize_bilinear_u8``, bit-exact with Pillow's bilinear resampler, which is what
+  torchvision's PIL backend calls; without a device argument Pillow does it on the host), the uint8 → normalised-float step is
+  ``ops.normalize_u8`` or the stem itself (3 bytes per pixel cross PCIe instead of 12);
+* single-image prediction — `src/testing.py:532-595` ``predict_image``: Resize → ToTensor → Normalize → forward → softmax → max;
 * evaluation step — `src/testing.py:255-283`: forward → softmax → arg-max, with the ArcFace branch
   scoring embeddings against the class centres (`:264-269`; `hyperparameter_tuning.py:1038-1046`);
 * Siamese verification — `src/testing.py:170-177`: ``dist = pairwise_distance(out1, out2)``,
@@ -238,3 +240,54 @@ def evaluate_model(model, model_type: str, test_data, class_names: Optional[Sequ
             json.dump({"model_type": model_type, "model_name": model_name or model_type, "dataset": dataset_name,
                        "metrics": metrics, "class_names": list(class_names)}, f, indent=2)
     return model_results
+
+
+# ------------------------------------------------------------------------------------------------
+# `src/testing.py:532-595`: predict_image
+# ------------------------------------------------------------------------------------------------
+def predict_image(model_type: str, image_path: str, model_name: Optional[str] = None, checkpoints_dir: str = "outputs/checkpoints",
+                  proc_data_dir: str = "data/processed", device="cuda") -> Tuple[str, float]:
+    """Make a prediction for a single image: ``(class_name, probability)`` - `src/testing.py:532-595` on the HIP path.
+
+    Same discovery rules and errors as the reference: the latest ``<model_type>_*`` directory under ``checkpoints_dir``
+    (``CHECKPOINTS_DIR``, `base_config.py:18`) unless ``model_name`` is given; class names from ``ImageFolder(<first processed
+    dataset>/train)`` under ``proc_data_dir`` (``PROC_DATA_DIR``, `base_config.py:15`); ``best_model.pth`` before
+    ``best_checkpoint.pth``; ``'siamese'`` is refused.  The image is resized to 224x224 on the device (bit-exact with the PIL
+    bilinear ``transforms.Resize``), ToTensor + Normalize run inside the stem, then forward -> softmax -> max.
+    Checkpoints are read with ``weights_only=True`` (a ``state_dict`` of tensors; nothing in the file is executed)."""
+    import os
+    from pathlib import Path
+    from PIL import Image
+    from .face_models import get_model
+    ckpt_root, proc_root = Path(checkpoints_dir), Path(proc_data_dir)
+    if model_name is None:
+        model_dirs = list(ckpt_root.glob(f'{model_type}_*'))
+        if not model_dirs:
+            raise ValueError(f"No trained models found for type: {model_type}")
+        model_name = sorted(model_dirs)[-1].name
+    model_checkpoint_dir = ckpt_root / model_name
+    if not model_checkpoint_dir.exists():
+        raise ValueError(f"Model not found: {model_name}")
+    processed_dirs = [d for d in proc_root.iterdir() if d.is_dir() and (d / "train").exists()] if proc_root.exists() else []
+    if not processed_dirs:
+        raise ValueError("No processed datasets found.")
+    if model_type == 'siamese':
+        raise ValueError("Siamese model can't be used for direct prediction. Use it for verification.")
+    classes = sorted(d.name for d in os.scandir(processed_dirs[0] / "train") if d.is_dir())   # ImageFolder(...).classes
+    with Image.open(image_path) as im:
+        u8 = resize_to_u8([im.convert('RGB')], (224, 224), device=device)                    # uint8 [1, 224, 224, 3] on the device
+    model = get_model(model_type, num_classes=len(classes)).to(device)
+    best_model_path, best_checkpoint_path = model_checkpoint_dir / 'best_model.pth', model_checkpoint_dir / 'best_checkpoint.pth'
+    if best_model_path.exists():
+        model.load_state_dict(torch.load(best_model_path, map_location=device, weights_only=True))
+    elif best_checkpoint_path.exists():
+        model.load_state_dict(torch.load(best_checkpoint_path, map_location=device, weights_only=True))
+    else:
+        raise FileNotFoundError(f"Neither best_model.pth nor best_checkpoint.pth found in {model_checkpoint_dir}")
+    model.eval()
+    with torch.no_grad():
+        x = u8 if getattr(model, "supports_u8_input", False) else preprocess(u8, IMAGENET_MEAN, IMAGENET_STD, device)
+        outputs = model(x)
+        probs, pred = ops.softmax_argmax(outputs)
+        pred_idx = int(pred[0])
+        return classes[pred_idx], float(probs[0, pred_idx])

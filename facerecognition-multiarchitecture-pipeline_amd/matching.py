@@ -33,7 +33,9 @@ _save_counter = 0
 
 
 class Gallery:
-    """Device-resident gallery: names + one fp32 G×D matrix (row i = reference i's embedding)."""
+    """Device-resident gallery: names + one fp32 G×D matrix (row i = reference i's embedding), held in a buffer with spare
+    capacity so that enrolling an identity (`app.py:428-436` appends one entry) writes ONE row - and, for galleries on the MFMA
+    match path, re-packs one 64-row tile - instead of rebuilding and re-uploading everything."""
 
     def __init__(self, names: Sequence[str], embeddings: torch.Tensor, device: Union[str, torch.device] = "cuda"):
         emb = embeddings.detach().to(torch.float32)
@@ -42,24 +44,68 @@ class Gallery:
         if emb.dim() != 2 or emb.shape[0] != len(names):
             raise ValueError("Gallery: need one D-vector per name")
         self.names = list(names)
-        self.matrix = emb.to(device).contiguous()
+        self._buf = emb.to(device).contiguous()          # [capacity][D]; rows >= len(names) are spare
         self._pack = None
+        self._refresh_pack()
+
+    @property
+    def matrix(self) -> torch.Tensor:
+        return self._buf[: len(self.names)]
+
+    def _wants_pack(self) -> bool:
+        return len(self.names) >= ops.MATCH_MFMA_MIN_G and self._buf.shape[1] % 32 == 0 and _MFMA_MATCH
+
+    def _refresh_pack(self) -> None:
+        # built HERE (construction / enrolment time, on the caller's stream) and guarded by an event - not lazily on whichever
+        # side stream first matches against it
+        if self._wants_pack() and (self._pack is None or not self._pack.matches(self.matrix)):
+            with torch.cuda.device(self._buf.device):
+                self._pack = ops.MatchPack(self.matrix, capacity=self._buf.shape[0])
 
     @property
     def prepared(self):
-        """The gallery split for the MFMA match path (built on first use for galleries of >= `ops.MATCH_MFMA_MIN_G` rows)."""
-        if len(self.names) < ops.MATCH_MFMA_MIN_G or self.matrix.shape[1] % 32 or not _MFMA_MATCH:
+        """The gallery split for the MFMA match path (galleries of >= `ops.MATCH_MFMA_MIN_G` rows), else None."""
+        if not self._wants_pack():
             return None
-        if self._pack is None or not self._pack.matches(self.matrix):
-            self._pack = ops.match_prepare(self.matrix)
+        self._refresh_pack()         # (someone wrote into `matrix` behind our back: rebuild rather than match stale rows)
         return self._pack
+
+    def append(self, name: str, embedding: torch.Tensor) -> int:
+        """Enrol one identity (`app.py:428-436`): returns its row.  One row is written on the device; the MFMA pack (if any)
+        re-packs only that row's tile.  Capacity doubles when exhausted."""
+        e = embedding.detach().reshape(-1).to(torch.float32)
+        G, D = len(self.names), self._buf.shape[1]
+        if G == 0 and D != e.numel():
+            self._buf = torch.empty((16, e.numel()), dtype=torch.float32, device=self._buf.device)
+            D = e.numel()
+        if e.numel() != D:
+            raise ValueError(f"Gallery.append: embedding has {e.numel()} values, the gallery rows have {D}")
+        with torch.cuda.device(self._buf.device):
+            if G == self._buf.shape[0]:
+                cap = max(2 * G, 16)
+                cap = (cap + 255) // 256 * 256 if cap >= ops.MATCH_MFMA_MIN_G // 2 else cap
+                grown = torch.empty((cap, D), dtype=torch.float32, device=self._buf.device)
+                grown[:G] = self._buf[:G]
+                self._buf, self._pack = grown, None
+            self._buf[G].copy_(e.to(self._buf.device), non_blocking=True)
+            self.names.append(name)
+            if self._wants_pack():
+                if self._pack is not None and self._pack.src_ptr == self._buf.data_ptr() and self._pack.G == G:
+                    self._pack.update_rows(self.matrix, G, G + 1)
+                else:
+                    self._pack = ops.MatchPack(self.matrix, capacity=self._buf.shape[0])
+        return G
 
     @classmethod
     def from_refs(cls, refs: Sequence[dict], device: Union[str, torch.device] = "cuda") -> "Gallery":
         if not refs:
             return cls([], torch.zeros((0, 1)), device)
-        rows = [r["embedding"].detach().reshape(-1).to(torch.float32).cpu() for r in refs]
-        return cls([r["name"] for r in refs], torch.stack(rows), device)
+        rows = [r["embedding"].detach().reshape(-1) for r in refs]
+        if len({(t.device, t.dtype) for t in rows}) == 1:
+            mat = torch.stack(rows)                      # one gather on the tensors' own device, one transfer
+        else:
+            mat = torch.stack([t.to(torch.float32).cpu() for t in rows])
+        return cls([r["name"] for r in refs], mat, device)
 
     def __len__(self):
         return len(self.names)
@@ -68,32 +114,44 @@ class Gallery:
 _gallery_cache: dict = {}
 
 
+def _ref_tag(r) -> tuple:
+    e = r.get("embedding") if isinstance(r, dict) else None
+    if isinstance(e, torch.Tensor):
+        return (id(e), e.data_ptr(), e._version, tuple(e.shape), r.get("name"))
+    return (id(e), r.get("name") if isinstance(r, dict) else None)
+
+
 def _refs_tag(refs) -> tuple:
     """Content tag of a ``refs`` list: per entry the embedding object's identity, storage address and in-place
     version counter — an in-place edit of an enrolled embedding, a replaced entry or a list that was freed and
     reallocated at the same ``id`` all change it."""
-    tag = [len(refs)]
-    for r in refs:
-        e = r.get("embedding") if isinstance(r, dict) else None
-        if isinstance(e, torch.Tensor):
-            tag.append((id(e), e.data_ptr(), e._version, tuple(e.shape), r.get("name")))
-        else:
-            tag.append((id(e), r.get("name") if isinstance(r, dict) else None))
-    return tuple(tag)
+    return (len(refs),) + tuple(_ref_tag(r) for r in refs)
 
 
 def _as_gallery(refs, device) -> Gallery:
     if isinstance(refs, Gallery):
         return refs
-    # the demo passes the same list object every frame (`app.py:639`): keep its device matrix while the list is unchanged
+    # the demo passes the same list object every frame (`app.py:639`): keep its device matrix while the list is unchanged,
+    # and when entries were only APPENDED (enrolment, `app.py:428-436`) append their rows instead of rebuilding
     key = id(refs)
     tag = _refs_tag(refs)
     dev = torch.device(device)
     if dev.type == "cuda" and dev.index is None:
         dev = torch.device("cuda", torch.cuda.current_device())
     hit = _gallery_cache.get(key)
-    if hit is not None and hit[0] == tag and hit[1].matrix.device == dev:
-        return hit[1]
+    if hit is not None and hit[1].matrix.device == dev:
+        old_tag, g = hit
+        if old_tag == tag:
+            return g
+        n_old = old_tag[0]
+        if 0 < n_old < tag[0] and tag[1: 1 + n_old] == old_tag[1:] and len(g) == n_old:
+            try:
+                for r in refs[n_old:]:
+                    g.append(r["name"], r["embedding"])
+                _gallery_cache[key] = (tag, g)
+                return g
+            except Exception:
+                pass                                     # (ragged entry: fall through to the full rebuild and its error)
     g = Gallery.from_refs(refs, dev)
     if len(_gallery_cache) > 8:
         _gallery_cache.clear()
@@ -132,9 +190,12 @@ def compare_faces(emb, refs, thresh):
     dev = emb.device if emb.is_cuda else torch.device("cuda")
     g = _as_gallery(refs, dev)
     e = emb.detach().reshape(1, -1).to(device=dev, dtype=torch.float32)
-    idx, dist = match_batch(e, g)
-    best_ref_idx = int(idx.item())
-    min_dist = float(dist.item())
+    # one launch sequence, ONE device -> host copy: the int32 [1, 2] record (index, bits of the distance)
+    rec = ops.match_top1(e, g.matrix, float("inf"), packed=True, prepared=g.prepared)[3].cpu()
+    best_ref_idx = int(rec[0, 0])
+    min_dist = float(rec.view(torch.float32)[0, 1])
+    if best_ref_idx < 0:                                  # every distance NaN: the reference's loop never updates its minimum
+        return "Unknown", float('inf'), None
     if min_dist <= thresh:
         return g.names[best_ref_idx], min_dist, best_ref_idx
     return "Unknown", min_dist, None
@@ -277,10 +338,7 @@ def load_refs(ref_file: Optional[str] = None) -> List[dict]:
     try:
         for rec in gallery_io.read_gallery_file(ref_file):
             p = rec["image_path"]
-            if p and not os.path.isabs(p) and not os.path.exists(p):
-                alt = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(ref_file))), p)
-                p = alt if os.path.exists(alt) else p
-            if p and os.path.exists(p):
+            if p and os.path.exists(p):                   # as stored, relative to the working directory (`app.py:110`)
                 img = _imread_bgr(p)
                 if img is not None:
                     refs.append({'name': rec['name'], 'embedding': torch.tensor(rec['embedding_numpy']).cpu(),

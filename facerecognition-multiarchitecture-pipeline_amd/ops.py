@@ -477,18 +477,38 @@ def _packed_buf(packed, B: int, device):
 
 class MatchPack:
     """A gallery prepared for the MFMA match path (`frmap_match_pack_gallery`): the fp32 rows split into fp16 (hi, lo)
-    pairs in the GEMM kernel's operand order, plus the per-row statistics of the expanded distance."""
-    __slots__ = ("packed", "stat_w", "G", "D", "src_ptr", "src_version")
+    pairs in the GEMM kernel's operand order, plus the per-row statistics of the expanded distance.  ``capacity`` > G
+    leaves room for `update_rows` (incremental enrolment: only the touched 64-row tiles are re-packed)."""
+    __slots__ = ("packed", "stat_w", "G", "D", "capacity", "src_ptr", "src_version", "ready")
 
-    def __init__(self, gallery: torch.Tensor):
+    def __init__(self, gallery: torch.Tensor, capacity: Optional[int] = None):
         gallery = _dev(gallery, "match_prepare.gallery", torch.float32)
         self.G, self.D = int(gallery.shape[0]), int(gallery.shape[1])
+        self.capacity = max(int(capacity or 0), self.G)
         lib = _lib.load()
-        self.packed = torch.empty((lib.frmap_match_gallery_pack_bytes(self.G, self.D),), dtype=torch.uint8, device=gallery.device)
-        self.stat_w = torch.empty((self.G, 4), dtype=torch.float32, device=gallery.device)
+        self.packed = torch.empty((lib.frmap_match_gallery_pack_bytes(self.capacity, self.D),), dtype=torch.uint8, device=gallery.device)
+        self.stat_w = torch.empty((self.capacity, 4), dtype=torch.float32, device=gallery.device)
         self.src_ptr, self.src_version = gallery.data_ptr(), gallery._version
         _lib.check(lib.frmap_match_pack_gallery(gallery.data_ptr(), self.packed.data_ptr(), self.stat_w.data_ptr(), self.G, self.D,
                                                 _stream()), "match_pack_gallery")
+        self.ready = torch.cuda.Event()
+        self.ready.record()          # consumers on other streams wait for the pack kernels (`wait_ready`)
+
+    def update_rows(self, gallery: torch.Tensor, row_lo: int, row_hi: int) -> None:
+        """``gallery`` (same storage, now G rows) had rows [row_lo, row_hi) appended or edited: re-pack those rows only."""
+        gallery = _dev(gallery, "match_update.gallery", torch.float32)
+        G = int(gallery.shape[0])
+        if gallery.data_ptr() != self.src_ptr or gallery.shape[1] != self.D or G > self.capacity:
+            raise ValueError("MatchPack.update_rows: not the gallery storage this pack was built from (or beyond its capacity)")
+        torch.cuda.current_stream().wait_event(self.ready)
+        _lib.check(_lib.load().frmap_match_pack_gallery_rows(gallery.data_ptr(), self.packed.data_ptr(), self.stat_w.data_ptr(),
+                                                             int(row_lo), int(row_hi), G, self.D, _stream()), "match_pack_gallery_rows")
+        self.G, self.src_version = G, gallery._version
+        self.ready = torch.cuda.Event()
+        self.ready.record()
+
+    def wait_ready(self) -> None:
+        torch.cuda.current_stream().wait_event(self.ready)
 
     def matches(self, gallery: torch.Tensor) -> bool:
         return (gallery.data_ptr() == self.src_ptr and gallery._version == self.src_version and
@@ -520,6 +540,7 @@ def match_top1(emb: torch.Tensor, gallery: torch.Tensor, thresh: Optional[float]
         dist = torch.empty((B,), dtype=torch.float32, device=emb.device)
         if D != prepared.D:
             raise ValueError(f"match_top1: embedding dim {D} != prepared gallery dim {prepared.D}")
+        prepared.wait_ready()
         ws = _match_workspace(B, G, emb.device)       # candidate records + per-probe statistics
         split = torch.empty((B, 3 * D), dtype=torch.float16, device=emb.device)
         ids = torch.empty((B,), dtype=torch.int32, device=emb.device) if thresh is not None else None
@@ -726,6 +747,7 @@ class ModelHandle:
                 if prepared is not None and G >= MATCH_MFMA_MIN_G:
                     if not prepared.matches(gallery):
                         raise ValueError("embed_and_match: `prepared` was built from a different (or since modified) gallery")
+                    prepared.wait_ready()
                     ppk, pst = prepared.packed.data_ptr(), prepared.stat_w.data_ptr()
             idx = torch.empty((B,), dtype=torch.int32, device=x.device)
             dist = torch.empty((B,), dtype=torch.float32, device=x.device)

@@ -169,6 +169,12 @@ int frmap_conv_pp_tuning(int enable, int tile_px, int bn);
  * MFMAs of k-step k (conv3x3_pp_kernel<..., RI = true>) where the layout allows, 0 = one burst per phase, -1 = environment
  * (FRMAP_PP_RI). */
 int frmap_conv_pp_ri(int v);
+/* Further process-wide A/B hooks of the same kernel family (experiments recorded in DESIGN.md; defaults = the shipped path):
+ * frmap_conv_pp_pitch: conflict-free LDS halo pitch on (1) / off (0); frmap_conv_pp_ds: the fused projection-shortcut form
+ * on the second-generation kernel on (1) / off (0); frmap_conv_pp_im: LDS-DMA issued between the MFMAs (1) or in a burst (0). */
+int frmap_conv_pp_pitch(int v);
+int frmap_conv_pp_ds(int v);
+int frmap_conv_pp_im(int v);
 /* Which layout frmap_conv_igemm gives a 3x3 stride-1 pad-1 layer without a fused shortcut: 0 = a first-generation
  * kernel; conv3x3_pp_kernel with 1 = 224 px x 256 ch tiles, 2 = 448 px x 128 ch, 3 = 224 px x 128 ch split-K. */
 int frmap_conv3x3_pp_layout(int B, int Hi, int Wi, int Cin, int Cout);
@@ -313,6 +319,11 @@ int frmap_match_top1(const float* emb, const float* gallery, int32_t* idx_out, f
  * (candidates are re-scored from it). */
 size_t frmap_match_gallery_pack_bytes(int G, int D);
 int frmap_match_pack_gallery(const float* gallery, void* packed_out, float* stat_w_out, int G, int D, void* stream);
+/* Incremental enrolment (src/app.py:428-436 appends one identity and re-saves): rows [row_lo, row_hi) of a gallery that now
+ * holds G rows were appended (row_hi == G) or edited in place; only their statistics and the 64-row tiles they touch are
+ * re-packed.  packed_out / stat_w_out must be sized for the gallery's CAPACITY (>= G rows). */
+int frmap_match_pack_gallery_rows(const float* gallery, void* packed_out, float* stat_w_out, int row_lo, int row_hi,
+                                  int G, int D, void* stream);
 int frmap_match_top1_packed(const float* emb, const float* gallery, const void* gallery_packed, const float* stat_w,
                             int32_t* idx_out, float* dist_out, int32_t* id_or_unknown_out, int32_t* packed_out,
                             float thresh, void* workspace, void* probe_split, int B, int G, int D, void* stream);

@@ -459,3 +459,111 @@ def test_gallery_prepared_pack_lifecycle():
     idx2, _ = matching.match_batch(probes[1:2], big)
     idx2_32, _ = ops.match_top1(probes[1:2], big.matrix)
     assert torch.equal(idx2, idx2_32)
+
+
+def test_compare_faces_sees_appended_edited_replaced_and_reallocated_refs():
+    """`matching._as_gallery` keeps a device copy of the demo's `refs` list between frames (`app.py:639` passes the same list
+    object every frame).  Whatever the host does to that list - enrol an identity (`app.py:428-436`: append), edit an enrolled
+    embedding in place, replace an entry, free the list and build another - the next `compare_faces` must answer from the
+    CURRENT contents, as the reference's loop over the live list does.  Small (exact-scan) and large (MFMA pack) galleries."""
+    from frmap_amd import matching
+    for G in (7, 600):
+        emb = synth.unit_rows(8100 + G, G + 4, 512, "g")
+        refs = [{"name": f"id{i}", "embedding": emb[i:i + 1].clone()} for i in range(G)]
+        probe = emb[G:G + 1]                                                   # not enrolled yet
+        want = fo.compare_faces(probe, refs, 10.0)
+        got = frmap_amd.compare_faces(probe.to(DEV), refs, 10.0)
+        assert (got[0], got[2]) == (want[0], want[2]) and abs(got[1] - want[1]) < 2e-6
+        g0 = matching._gallery_cache[id(refs)][1]
+        refs.append({"name": "new", "embedding": probe.clone()})               # enrolment: append
+        got = frmap_amd.compare_faces(probe.to(DEV), refs, 10.0)
+        assert (got[0], got[2]) == ("new", G) and abs(got[1] - math.sqrt(512) * 1e-6) < 2e-6
+        assert matching._gallery_cache[id(refs)][1] is g0 and len(g0) == G + 1  # one row appended on the device, no rebuild
+        refs[2]["embedding"].copy_(probe)                                      # in-place edit of an enrolled embedding
+        got = frmap_amd.compare_faces(probe.to(DEV), refs, 10.0)
+        assert (got[0], got[2]) == ("id2", 2)                                  # first strict minimum: row 2 now ties with the appended row
+        refs[1] = {"name": "swapped", "embedding": probe.clone()}              # replaced entry
+        got = frmap_amd.compare_faces(probe.to(DEV), refs, 10.0)
+        assert (got[0], got[2]) == ("swapped", 1)
+        assert fo.compare_faces(probe, refs, 10.0)[2] == 1
+        del refs[1:3]                                                          # removal
+        want = fo.compare_faces(probe, refs, 10.0)
+        got = frmap_amd.compare_faces(probe.to(DEV), refs, 10.0)
+        assert (got[0], got[2]) == (want[0], want[2]) == ("new", G - 2)
+    for trial in range(6):                                                     # freed-and-reallocated lists (ids may repeat)
+        e = synth.unit_rows(8200 + trial, 5, 512, "g")
+        lst = [{"name": f"t{trial}_{i}", "embedding": e[i:i + 1]} for i in range(4)]
+        got = frmap_amd.compare_faces(e[3:4].to(DEV), lst, 10.0)
+        assert (got[0], got[2]) == (f"t{trial}_3", 3)
+        del lst
+
+
+def test_gallery_append_equals_rebuild():
+    """`Gallery.append` (one row written, one 64-row tile of the MFMA pack re-packed, capacity doubling) leaves exactly the
+    gallery a fresh build holds: same pack bytes, same statistics, same match results - across a capacity regrow and across
+    256-row padding boundaries of the pack."""
+    from frmap_amd import _lib
+    rows = synth.unit_rows(8300, 1400, 512, "g")
+    g = frmap_amd.Gallery([f"id{i}" for i in range(1000)], rows[:1000], DEV)
+    assert g.prepared is not None
+    for i in range(1000, 1400):
+        assert g.append(f"id{i}", rows[i]) == i
+    fresh = frmap_amd.Gallery([f"id{i}" for i in range(1400)], rows, DEV)
+    assert len(g) == 1400 and torch.equal(g.matrix, fresh.matrix)
+    nb = _lib.load().frmap_match_gallery_pack_bytes(1400, 512)
+    torch.cuda.synchronize()
+    assert torch.equal(g.prepared.packed[:nb], fresh.prepared.packed[:nb])
+    assert torch.equal(g.prepared.stat_w[:1400], fresh.prepared.stat_w[:1400])
+    probes = (rows[[5, 1000, 1023, 1024, 1279, 1280, 1399]] + 1e-3 * synth.randn(8301, (7, 512), "n")).to(DEV)
+    idx, dist = frmap_amd.match_batch(probes, g)
+    idx_f, dist_f = frmap_amd.match_batch(probes, fresh)
+    assert idx.tolist() == [5, 1000, 1023, 1024, 1279, 1280, 1399] and torch.equal(idx, idx_f) and torch.equal(dist, dist_f)
+    small = frmap_amd.Gallery([], torch.zeros((0, 1)), DEV)                     # enrolment from an empty gallery
+    for i in range(40):
+        small.append(f"s{i}", rows[i])
+    idx, _ = frmap_amd.match_batch(rows[[0, 17, 39]].to(DEV), small)
+    assert idx.tolist() == [0, 17, 39] and small.prepared is None
+    with pytest.raises(ValueError):
+        small.append("bad", rows[0][:256])
+
+
+def test_predict_image_mirror(tmp_path, calibrated_sd):
+    """`src/testing.py:532-595`: latest `<type>_*` checkpoint directory, class names from `<processed>/<dataset>/train`,
+    Resize((224, 224)) -> ToTensor -> Normalize -> forward -> softmax -> max -> (class name, probability); against the oracle on
+    the Pillow-resized pixels; the reference's error paths."""
+    from PIL import Image
+    from frmap_amd import evaluate
+    ck, proc = tmp_path / "checkpoints", tmp_path / "processed"
+    classes = [f"person_{i:02d}" for i in range(36)]
+    for c in classes:
+        (proc / "lfw" / "train" / c).mkdir(parents=True)
+    g = np.random.Generator(np.random.PCG64(77))
+    img = tmp_path / "probe.png"
+    Image.fromarray(g.integers(0, 256, (301, 263, 3), dtype=np.uint8)).save(img)
+    with pytest.raises(ValueError, match="No trained models found for type: baseline"):
+        evaluate.predict_image("baseline", str(img), checkpoints_dir=str(ck), proc_data_dir=str(proc))
+    for mt in ("baseline", "cnn"):
+        sd = calibrated_sd(mt)
+        for ver in ("v1", "v2"):
+            (ck / f"{mt}_{ver}").mkdir(parents=True)
+        torch.save(sd, ck / f"{mt}_v2" / "best_model.pth")                      # the LATEST directory is the one used (`:538-541`)
+        name, prob = evaluate.predict_image(mt, str(img), checkpoints_dir=str(ck), proc_data_dir=str(proc))
+        u8 = evaluate.resize_to_u8([Image.open(img)])                           # Pillow on the host
+        x = (u8.permute(0, 3, 1, 2).float() / 255 - torch.tensor(evaluate.IMAGENET_MEAN).view(1, 3, 1, 1)) / torch.tensor(evaluate.IMAGENET_STD).view(1, 3, 1, 1)
+        with torch.no_grad():
+            p = torch.softmax(fo.FORWARD[mt](sd, x), dim=1)
+        want_p, want_i = p.max(dim=1)
+        top2 = p.topk(2, dim=1).values[0]
+        print(f"predict_image {mt}: {name} p={prob:.4f} oracle {classes[int(want_i)]} p={float(want_p):.4f}")
+        assert abs(prob - float(want_p)) < 5e-3
+        if float(top2[0] - top2[1]) > 1e-2:
+            assert name == classes[int(want_i)]
+        with pytest.raises(FileNotFoundError):
+            evaluate.predict_image(mt, str(img), model_name=f"{mt}_v1", checkpoints_dir=str(ck), proc_data_dir=str(proc))
+    with pytest.raises(ValueError, match="Model not found: cnn_v9"):
+        evaluate.predict_image("cnn", str(img), model_name="cnn_v9", checkpoints_dir=str(ck), proc_data_dir=str(proc))
+    (ck / "siamese_v1").mkdir()
+    with pytest.raises(ValueError, match="Siamese model can't be used for direct prediction"):
+        evaluate.predict_image("siamese", str(img), checkpoints_dir=str(ck), proc_data_dir=str(proc))
+    with pytest.raises(ValueError, match="No processed datasets found"):
+        evaluate.predict_image("cnn", str(img), checkpoints_dir=str(ck), proc_data_dir=str(tmp_path / "nowhere"))

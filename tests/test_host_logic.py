@@ -110,6 +110,11 @@ def test_cabi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.frmap_abi_version() == _lib.ABI_VERSION
+    # ... and nothing undeclared: every `frmap_*` symbol the library exports with C linkage is in the header
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if ln.split() and ln.split()[-1].startswith("frmap_")}
+    assert exported == declared, exported ^ declared
     assert lib.frmap_small_cin_kpad(7, 7) == 240 and lib.frmap_small_cin_kpad(3, 3) == 80   # K + 16: the bank-conflict-free pitch
     assert lib.frmap_head_workspace_bytes(4, 4) >= 8 * 16
 
