@@ -21,10 +21,41 @@ for f in conv_igemm.hip conv_pp.hip conv_small_cin.hip stem_pool.hip layout_pool
   fi
   objs+=("$o")
 done
+# The second-generation kernels order their LDS-DMA by hand-counted `s_waitcnt vmcnt(n)`; a scratch spill inside such a loop
+# is a vector-memory access the count does not know about (stale LDS could be read).  Every *_pp_kernel must therefore compile
+# without scratch: check the resource-usage remarks of conv_pp.hip (one extra, parallel, compile; FRMAP_SKIP_SPILL_CHECK=1 skips it).
+spill_pid=""
+if [ "${FRMAP_SKIP_SPILL_CHECK:-0}" != "1" ] && { [ ! -f .pp_spill_ok ] || [ conv_pp.hip -nt .pp_spill_ok ] || [ frmap_common.h -nt .pp_spill_ok ]; }; then
+  ( $HIPCC $FLAGS -Rpass-analysis=kernel-resource-usage -c conv_pp.hip -o /dev/null 2> .pp_remarks.txt || exit 1
+    python3 - <<'PY' || exit 1
+import re, sys
+blocks = open(".pp_remarks.txt").read().split("remark: Function Name: ")[1:]
+bad = []
+for b in blocks:
+    name = b.split(" ")[0]
+    if "pp_kernel" not in name:
+        continue
+    sc = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+    sp = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
+    if sc or sp:
+        bad.append((name, sc, sp))
+if not blocks:
+    sys.exit("spill check: no resource-usage remarks parsed")
+for name, sc, sp in bad:
+    print(f"spill check: {name} uses {sc} B/lane of scratch ({sp} VGPRs spilled)", file=sys.stderr)
+sys.exit(1 if bad else 0)
+PY
+    touch .pp_spill_ok ) &
+  spill_pid=$!
+fi
 fail=0
 for p in "${pids[@]:-}"; do
   if [ -n "$p" ] && ! wait "$p"; then fail=1; fi
 done
+if [ -n "$spill_pid" ] && ! wait "$spill_pid"; then
+  echo "build failed: a *_pp_kernel spills registers (see above)" >&2
+  exit 1
+fi
 if [ "$fail" != 0 ]; then
   echo "build failed" >&2
   exit 1

@@ -47,7 +47,7 @@ struct ConvParams {
   int ds_Hi, ds_Wi, ds_Cin, ds_stride, ds_chunks;
   FrmapPoolOrder pool;  // conv_igemm_kernel<..., POOL = true>: pool-major pixel order of the fused 2x2 max-pool
   // conv1x1_kernel<..., MATCH = true>: the GEMM is probes x gallery rows, the epilogue keeps each probe's arg-min distance
-  const float* m_stat_a;           // [M][4] = (sum a^2, sum a, 1 / row scale, row scale) of the fp32 probes
+  const float* m_stat_a;           // [M][4] = (sum a^2, sum a, 1 / row scale, error band) of the fp32 probes
   const float* m_stat_w;           // [G][4] of the fp32 gallery rows
   MatchRec* m_recs;                // [Cout / 64][M] candidate records (frmap_common.h), one writer each
   int m_G, m_D;                    // real gallery rows (Cout is padded to 64), embedding width

@@ -55,7 +55,7 @@ struct PPParams {
   int Wo2;         // Wi / 2
   FrmapDiv dWo2;
   // conv1x1_pp_kernel<..., MATCH = true> (top-1 gallery match, head_match.hip): per-row statistics and the arg-min keys
-  const float* m_stat_a;        // [M][4] = (sum a^2, sum a, 1 / row scale, row scale) of the fp32 probes
+  const float* m_stat_a;        // [M][4] = (sum a^2, sum a, 1 / row scale, error band) of the fp32 probes
   const float* m_stat_w;        // [G][4] of the fp32 gallery rows
   MatchRec* m_recs;             // [Cout / 64][M] candidate records (frmap_common.h), one writer each
   int m_G, m_D;
@@ -1011,9 +1011,11 @@ int frmap_conv3x3_pp(const void* in, const void* w_packed, const float* shift, c
 #undef PPD_GO
     return rc ? rc : 1;
   }
-  if (ri_want) {
+  // (the RI form of the split-K layout with 6 halo pieces needs 258 VGPRs: it would spill inside the DMA-counted loop, so that
+  //  one layout keeps the burst-read form; csrc/build.sh rejects any *_pp_kernel with scratch)
+  if (ri_want && !(ks == 2 && nhp > 4)) {
 #define PPR_GO(TT)                                                                                              \
-  (ks == 2 ? (nhp <= 4 ? pp_launch_ri<TT, MI, 2, 4, 2>(p, st) : pp_launch_ri<TT, MI, 2, 6, 2>(p, st))            \
+  (ks == 2 ? pp_launch_ri<TT, MI, 2, 4, 2>(p, st)                                                               \
    : bn == 256 ? (nhp <= 3 ? pp_launch_ri<TT, MI, 2, 3, 1>(p, st) : pp_launch_ri<TT, MI, 2, 5, 1>(p, st))        \
                : (nhp <= 3 ? pp_launch_ri<TT, MI, 4, 3, 1>(p, st) : pp_launch_ri<TT, MI, 4, 5, 1>(p, st)))
     rc = dtype == FRMAP_BF16 ? PPR_GO(BF16) : PPR_GO(F16);

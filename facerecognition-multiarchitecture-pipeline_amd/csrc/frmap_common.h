@@ -93,6 +93,7 @@ __device__ __forceinline__ float match_band(float s2, float kf) { return s2 + 2e
 // Epilogue of the split-fp16 match GEMMs (conv1x1_kernel<.., MATCH>, conv1x1_pp_kernel<.., MATCH>): after the K loop lane
 // (lr, g) holds, per MFMA tile (mi, ni), the scaled dot products of probe b_base + mi * 16 + lr with gallery rows
 // n0 + ni * 16 + 4 g + j.  The wave's 64 gallery rows are one slot (n0 / 64); records are laid out [slot][M].
+// Row statistics (match_row_prep_kernel): (sum x^2, sum x, 1 / row scale, band(x)).
 template <int MI>
 __device__ __forceinline__ void match_epilogue_records(const f32x4_t (&acc)[MI][4], int b_base, int b_end, int n0, int G, int D,
                                                        int M, const float* __restrict__ stat_a,
@@ -100,36 +101,31 @@ __device__ __forceinline__ void match_epilogue_records(const f32x4_t (&acc)[MI][
                                                        int lane) {
   const int lr = lane & 15, g = lane >> 4;
   const float eps = 1e-6f, kf = (float)D, keps = kf * eps * eps, kap = match_kappa(3 * D);
-  float w2[4][4], ws[4][4], wi[4][4], wb[4][4];
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = min(n0 + ni * 16 + 4 * g + j, G - 1);
-      const f32x4_t sw = *(const f32x4_t*)(stat_w + 4 * (size_t)n);
-      w2[ni][j] = sw[0]; ws[ni][j] = sw[1]; wi[ni][j] = sw[2];
-      wb[ni][j] = match_band(sw[0], kf) + keps;
-    }
+  // One probe row (mi) at a time; the gallery-row statistics are re-read per (mi, ni) block (L1 hits) instead of being held for
+  // the whole epilogue, so the live set stays at acc + ~30 registers: the kernels around this epilogue count their LDS-DMA with
+  // s_waitcnt vmcnt(n) and must not spill (csrc/build.sh checks)
   MatchRec* out = recs + (size_t)(n0 >> 6) * M;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int b = b_base + mi * 16 + lr;
     const f32x4_t sa = *(const f32x4_t*)(stat_a + 4 * (size_t)min(b, M - 1));
-    const float a2 = sa[0], as = sa[1], ai = sa[2], ab = match_band(sa[0], kf);
+    const float a2 = sa[0], as = sa[1], ai = sa[2], ab = sa[3] + keps;
     float l1 = INFINITY, l2 = INFINITY, up = INFINITY;
     int i1 = -1;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
+    for (int ni = 0; ni < 4; ++ni) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int n = n0 + ni * 16 + 4 * g + j;
-        const float d2 = a2 + w2[ni][j] - 2.f * (acc[mi][ni][j] * ai * wi[ni][j]) + 2.f * eps * (as - ws[ni][j]) + keps;
-        const float dl = kap * (ab + wb[ni][j]);
+        const f32x4_t sw = *(const f32x4_t*)(stat_w + 4 * (size_t)min(n, G - 1));
+        const float d2 = a2 + sw[0] - 2.f * (acc[mi][ni][j] * ai * sw[2]) + 2.f * eps * (as - sw[1]) + keps;
+        const float dl = kap * (ab + sw[3]);
         const float L = n < G ? d2 - dl : INFINITY, U = n < G ? d2 + dl : INFINITY;
         if (L < l1) { l2 = l1; l1 = L; i1 = n; }   // rows ascend inside the lane: the first of equal L keeps the index,
         else if (L < l2) l2 = L;                   // the second lands in lo2 (= lo1: the whole slot is re-scored)
         up = fminf(up, U);
       }
+    }
 #pragma unroll
     for (int o = 16; o <= 32; o <<= 1) {
       const float ol1 = __shfl_xor(l1, o, 64), ol2 = __shfl_xor(l2, o, 64), ou = __shfl_xor(up, o, 64);
@@ -142,6 +138,7 @@ __device__ __forceinline__ void match_epilogue_records(const f32x4_t (&acc)[MI][
       MatchRec r; r.lo1 = l1; r.idx = i1; r.lo2 = l2; r.up = up;
       out[b] = r;
     }
+    __builtin_amdgcn_sched_barrier(0);   // one probe row's loads at a time: no hoisting of the next row's statistics loads
   }
 }
 

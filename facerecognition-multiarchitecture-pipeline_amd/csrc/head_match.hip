@@ -896,7 +896,7 @@ extern "C" int frmap_match_top1(const float* emb, const float* gallery, int32_t*
 // ------------------------------------------------------------------------------------------------
 // Each row gets its own power-of-two scale S (largest |x| of the row lands in [2^13, 2^14): nothing overflows fp16, lo stays
 // out of the fp16 subnormals for every element within 2^-11 of the row maximum, and scaling by a power of two is exact);
-// statistics record of a row: (sum x^2, sum x, 1 / S, S).
+// statistics record of a row: (sum x^2, sum x, 1 / S, band(x) = the row's share of the expanded distance's error bound, frmap_common.h).
 __device__ __forceinline__ float match_row_scale(float amax) {
   if (!(amax > 0.f) || isinf(amax)) return 1.f;
   int e;
@@ -921,7 +921,8 @@ __global__ void match_row_prep_kernel(const float* __restrict__ x, float* __rest
   }
   const float S = match_row_scale(amax);
   if (lane == 0) {
-    stat4[4 * (size_t)r] = s2; stat4[4 * (size_t)r + 1] = s1; stat4[4 * (size_t)r + 2] = 1.0f / S; stat4[4 * (size_t)r + 3] = S;
+    stat4[4 * (size_t)r] = s2; stat4[4 * (size_t)r + 1] = s1; stat4[4 * (size_t)r + 2] = 1.0f / S;
+    stat4[4 * (size_t)r + 3] = match_band(s2, (float)D);
   }
   if (split3) {
     _Float16* o = split3 + (size_t)r * 3 * D;
@@ -946,7 +947,7 @@ __global__ void match_pack_gallery_kernel(const float* __restrict__ gal, const f
     const int k3 = chunk * 32 + cg * 8 + j, row = ntile * 64 + cl;
     const int part = k3 / D, k = k3 - part * D;        // gallery side: (g_hi | g_lo | g_hi)
     float v = 0.f;
-    if (row < G) v = gal[(size_t)row * D + k] * stat4[4 * (size_t)row + 3];
+    if (row < G) v = gal[(size_t)row * D + k] * (1.0f / stat4[4 * (size_t)row + 2]);   // (S is a power of two: 1 / (1 / S) is exact)
     const _Float16 hi = (_Float16)v;
     out[e] = part == 1 ? (_Float16)(v - (float)hi) : hi;
   }
