@@ -13,7 +13,7 @@ import threading
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libfrmap_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _lock = threading.Lock()
 _lib = None
@@ -23,6 +23,7 @@ _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 # name -> (restype, argtypes); mirrors include/frmap_hip.h one to one
 PROTOTYPES = {
     "frmap_abi_version": (_i, []),
+    "frmap_set_batch_invariant": (_i, [_i]),
     "frmap_last_error": (C.c_char_p, []),
     "frmap_pack_input_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "frmap_pack_conv_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <mutex>
 #include <set>
@@ -42,5 +43,17 @@ int frmap_big_lds(const void* kern, int bytes) {
   return 0;
 }
 
-extern "C" int frmap_abi_version(void) { return 8; }
+// Batch-invariant planning (frmap_set_batch_invariant): the conv planners then choose a layer's kernel and tile layout from the
+// per-image geometry alone - never from the tile count, never split-K - so a face's result does not depend on the batch it
+// arrives in (a 1-face call and a 1024-face call give that face the same bits).  -1 = unset: environment FRMAP_BATCH_INVARIANT.
+static int g_invariant = -1;
+int frmap_batch_invariant() {
+  if (g_invariant >= 0) return g_invariant;
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("FRMAP_BATCH_INVARIANT"); env = (e && atoi(e) != 0) ? 1 : 0; }
+  return env;
+}
+extern "C" int frmap_set_batch_invariant(int on) { g_invariant = on < 0 ? -1 : (on != 0); return 0; }
+
+extern "C" int frmap_abi_version(void) { return 9; }
 extern "C" const char* frmap_last_error(void) { return g_err; }

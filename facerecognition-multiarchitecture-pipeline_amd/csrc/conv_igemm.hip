@@ -1523,7 +1523,8 @@ __global__ void splitk_finalize_kernel(const float* __restrict__ slab, int kspli
 }
 
 static int linear_ksplit(int M, int K, int N) {
-  const int tiles = ((M + 255) / 256) * (N / 64), nchunks = K / 32;
+  // (batch-invariant planning: the split - and with it the fp32 summation order - is that of a single row tile for every M)
+  const int tiles = (frmap_batch_invariant() ? 1 : (M + 255) / 256) * (N / 64), nchunks = K / 32;
   int ks = 384 / (tiles > 0 ? tiles : 1);
   if (ks > nchunks / 4) ks = nchunks / 4;
   return ks < 2 ? 1 : ks;

@@ -989,7 +989,8 @@ int frmap_conv3x3_pp(const void* in, const void* w_packed, const float* shift, c
   if (g_pp_bn == 128 || g_pp_bn == 256) bn_pref = (g_pp_bn == 256 && Cout % 256) ? 128 : g_pp_bn;
   int tpx = 0, mtl = 0, ntl = 0, ks = 1, bn = bn_pref;
   int nhp = plan(bn == 256 ? 2 * MI * 16 : 4 * MI * 16, bn, 1, tpx, mtl, ntl);
-  const bool want_ks2 = !has_ds && (g_pp_ks == 2 || (g_pp_ks < 0 && (!nhp || (long long)mtl * ntl < min_tiles)));
+  const bool inv = frmap_batch_invariant() != 0;   // layout from the per-image geometry alone: no tile-count rules, no split-K
+  const bool want_ks2 = !has_ds && !inv && (g_pp_ks == 2 || (g_pp_ks < 0 && (!nhp || (long long)mtl * ntl < min_tiles)));
   if (want_ks2 && g_pp_ks != 1) {
     int t2 = 0, m2 = 0, n2 = 0;
     const int nhp2 = plan(2 * MI * 16, 128, 2, t2, m2, n2);
@@ -999,8 +1000,8 @@ int frmap_conv3x3_pp(const void* in, const void* w_packed, const float* shift, c
   }
   if (!nhp) return 0;
   p.tile_px = tpx; p.mtiles = mtl; p.ntiles = ntl;
-  if (g_pp_on < 0 && (long long)mtl * ntl < min_tiles / 2) return 0;   // too few tiles even with split-K: the smaller first-generation tiles win
-  if (has_ds && (long long)mtl * ntl < min_tiles && g_pp_on < 0) return 0;   // (no split-K form of the shortcut kernel)
+  if (!inv && g_pp_on < 0 && (long long)mtl * ntl < min_tiles / 2) return 0;   // too few tiles even with split-K: the smaller first-generation tiles win
+  if (!inv && has_ds && (long long)mtl * ntl < min_tiles && g_pp_on < 0) return 0;   // (no split-K form of the shortcut kernel)
   if (!in) return ks == 2 ? 3 : (bn == 256 ? 1 : 2);                   // plan-only query (frmap_conv3x3_pp_layout)
   int rc;
   if (has_ds) {   // pixel-split layouts only; the 448-pixel layout needs the 40 KB halo buffers to hold a gather image
@@ -1118,6 +1119,7 @@ int frmap_conv1x1_pp(const void* in, const void* w_packed, const float* shift, c
     min_tiles = pp_env("FRMAP_PP_MIN_TILES", 200);
   }
   if (g_pp_on >= 0 ? !g_pp_on : !on) return 0;
+  if (frmap_batch_invariant() && g_pp_on < 0) return 0;   // (its layout is a rounds x time estimate over the tile count: the first-generation kernel's is not)
   if (Cin % 32 || Cin > 16384 || Cout % 128 || stride < 1) return 0;
   const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
   const long long Mll = (long long)B * Ho * Wo;
@@ -1280,7 +1282,7 @@ int frmap_conv3x3s2_pp(const void* in, const void* w_packed, const float* shift,
   const int need = (int)((hbytes + 8191) / 8192);
   const int nhp = need <= 1 ? 1 : (need <= 2 ? 2 : (need <= 4 ? 4 : 0));
   if (!nhp || (nhp == 4 && bn == 256)) return 0;                       // (4 x 32 KB images + 4 x 16 KB slabs would not fit)
-  if (g_pp_on < 0 && (long long)p.mtiles * p.ntiles < min_tiles) return 0;
+  if (!frmap_batch_invariant() && g_pp_on < 0 && (long long)p.mtiles * p.ntiles < min_tiles) return 0;
   if (!in) return bn == 256 ? 1 : 2;
   int rc;
 #define PP2_GO(TT)                                                                                                  \

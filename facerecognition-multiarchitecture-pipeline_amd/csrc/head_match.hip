@@ -576,7 +576,7 @@ template <typename TT, int FB, int NPT>
 __global__ __launch_bounds__(256) void gap_linear_norm_kernel(const typename TT::elem* __restrict__ map, const float* __restrict__ wt,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               float* __restrict__ pre_out, float* __restrict__ emb_out, float eps,
-                                                              int B, int HW, int K, int relu) {
+                                                              int B, int HW, int K, int relu, int stagger) {
   constexpr int N = NPT * 256;
   extern __shared__ float s_all[];
   float* s_x = s_all;                 // [K][FB]
@@ -650,8 +650,9 @@ __global__ __launch_bounds__(256) void gap_linear_norm_kernel(const typename TT:
 #pragma unroll
     for (int f = 0; f < FB; ++f) acc[j][f] = 0.f;
   // every workgroup reads the same K x N matrix: each starts at its own row block so that they do not all pull the same
-  // L2 lines at the same time
-  const int kstart = (int)(((long long)blockIdx.x * 40) % (K / 8)) * 8;
+  // L2 lines at the same time (stagger = 0 under batch-invariant planning: the summation order must not depend on where in
+  // the batch a face sits)
+  const int kstart = (int)(((long long)blockIdx.x * stagger) % (K / 8)) * 8;
   auto krow = [&](int it) { return it + kstart < K ? it + kstart : it + kstart - K; };
   float wc[8][NPT], wn[8][NPT];
   auto load_w = [&](float (&w)[8][NPT], int k0) {
@@ -741,7 +742,8 @@ extern "C" int frmap_gap_linear_norm(const void* map, const float* wt, const flo
   }
 #define GLN_GO(TT, ET, NPT)                                                                                                  \
   hipLaunchKernelGGL((gap_linear_norm_kernel<TT, FB, NPT>), grid, dim3(256), lds, st, (const ET*)map, wt, scale, shift, pre_out, \
-                     emb_out, eps, B, HW, K, relu)
+                     emb_out, eps, B, HW, K, relu, stagger)
+  const int stagger = frmap_batch_invariant() ? 0 : 40;
   if (dtype == FRMAP_BF16) { if (N == 512) GLN_GO(BF16, __bf16, 2); else GLN_GO(BF16, __bf16, 1); }
   else { if (N == 512) GLN_GO(F16, _Float16, 2); else GLN_GO(F16, _Float16, 1); }
 #undef GLN_GO

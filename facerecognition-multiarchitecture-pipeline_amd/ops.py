@@ -61,6 +61,13 @@ def dt_code(dtype: torch.dtype) -> int:
         raise TypeError(f"compute dtype must be torch.bfloat16 or torch.float16, got {dtype}") from None
 
 
+def set_batch_invariant(on: Optional[bool]) -> None:
+    """``True``: kernel / tile-layout choices depend on the per-image geometry only, so a face's result is bit-identical in
+    any batch, shard or rank (`frmap_set_batch_invariant`); ``False``: default planning (layouts follow the tile count: faster
+    at small batches, results of different batch sizes agree to rounding); ``None``: the environment (FRMAP_BATCH_INVARIANT)."""
+    _lib.check(_lib.load().frmap_set_batch_invariant(-1 if on is None else int(bool(on))), "set_batch_invariant")
+
+
 def pack_input(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """fp32 NCHW B×3×H×W -> NHWC4 (zero 4th channel) in ``dtype``."""
     x = _dev(x, "pack_input.x", torch.float32)

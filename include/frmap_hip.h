@@ -36,6 +36,14 @@ extern "C" {
 #define FRMAP_BF16 0
 #define FRMAP_F16 1
 
+/* Batch-invariant planning.  By default the conv / Linear planners pick a layer's kernel and tile layout from the number of
+ * tiles the launch would have (pixel split, in-workgroup split-K, first- or second-generation kernel), i.e. from the batch size:
+ * the same face then gets different fp32 summation orders - results equal to rounding, not to the bit - in batches of
+ * different sizes.  on = 1: layouts are chosen from the per-image geometry alone (never split-K by tile count), so a face's
+ * embedding and match are bit-identical whatever batch, shard or rank it is computed in, at some cost in speed for small
+ * batches.  on = 0: default planning; on = -1: back to the environment (FRMAP_BATCH_INVARIANT=1).  Process-wide. */
+int frmap_set_batch_invariant(int on);
+
 /* ABI version of this header (bumped on any signature change). */
 int frmap_abi_version(void);
 /* Text of the last rejected call on this thread ("" if none). Host pointer, do not free. */

@@ -65,6 +65,39 @@ def test_full_size_batch_properties():
         assert torch.equal(ids.cpu(), torch.where(dist[:64].cpu() <= 0.5, idx[:64].cpu(), torch.full((64,), -1, dtype=torch.int32)))
 
 
+@pytest.mark.parametrize("mt,dtype", [("arcface", torch.bfloat16), ("cnn", torch.float16)])
+def test_batch_invariant_mode_gives_every_face_the_same_bits_in_any_batch(mt, dtype):
+    """`ops.set_batch_invariant(True)` (`frmap_set_batch_invariant`): kernels and tile layouts are chosen from the per-image
+    geometry alone, so a face's embedding and its match record are BIT-identical whether it is computed alone, in a ragged
+    sub-batch, in a rank's shard or in the 1024-face batch - the unconditional form of SURVEY 4(iv) "1-rank vs 8-rank identical".
+    (Default planning: equal batch sizes give equal bits, different ones agree to rounding - the test above.)"""
+    m = frmap_amd.get_model(mt, 36)
+    m.load_state_dict(synth.calibrated_state_dict(mt, synth.shapes_of(m), {"arcface": 1004, "cnn": 1002}[mt]))
+    m = m.to(DEV).eval().set_compute_dtype(dtype)
+    g = torch.Generator(device=DEV); g.manual_seed(2104)
+    x = torch.randn((1024, 3, 224, 224), device=DEV, generator=g)
+    gal = frmap_amd.Gallery([str(i) for i in range(10000)], synth.unit_rows(3004, 10000, 512), DEV)
+    ops.set_batch_invariant(True)
+    try:
+        with torch.no_grad():
+            emb = m.get_embedding(x).reshape(1024, 512)
+            rec = frmap_amd.embed_and_match(m, x, gal, 1.5, normalize=(mt == "cnn"), packed=True)
+            for lo, hi in ((0, 1), (100, 117), (255, 257), (0, 256), (512, 1024), (1000, 1024)):
+                sub = m.get_embedding(x[lo:hi]).reshape(hi - lo, 512)
+                assert torch.equal(sub, emb[lo:hi]), (lo, hi)
+                rsub = frmap_amd.embed_and_match(m, x[lo:hi], gal, 1.5, normalize=(mt == "cnn"), packed=True)
+                assert torch.equal(rsub, rec[lo:hi]), (lo, hi)
+            parts = [frmap_amd.embed_and_match(m, x[lo:hi], gal, 1.5, normalize=(mt == "cnn"), packed=True)
+                     for lo, hi in (fdist.shard_bounds(1024, r, 8) for r in range(8))]
+            assert torch.equal(torch.cat(parts), rec)                       # 8 shards == 1 rank, bit for bit
+            pipe = frmap_amd.GraphedEmbedMatch(m, gal, x.clone(), 1.5, normalize=(mt == "cnn"), streams=2)
+            pipe()
+            torch.cuda.synchronize()
+            assert torch.equal(pipe.records, rec)                           # graph replay, 2 micro-batches of 512
+    finally:
+        ops.set_batch_invariant(None)
+
+
 @pytest.mark.parametrize("H,W", [(224, 224), (160, 160), (112, 96), (225, 231), (64, 64)])
 def test_input_sizes_and_batch_of_one(H, W):
     """The reference accepts any input size (adaptive pooling, face_models.py:30,43; input_size is
