@@ -12,7 +12,8 @@ import os
 import threading
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libfrmap_hip.so")
+# FRMAP_LIB: load another build of the library (A/B variants made by tools; must have the same ABI) instead of the in-tree one
+LIB_PATH = os.environ.get("FRMAP_LIB") or os.path.join(_PKG_DIR, "libfrmap_hip.so")
 ABI_VERSION = 9
 
 _lock = threading.Lock()

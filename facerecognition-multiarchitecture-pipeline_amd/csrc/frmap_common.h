@@ -341,6 +341,9 @@ __device__ __forceinline__ void frmap_pool_coords(int m, const FrmapPoolOrder& o
 void frmap_set_error(const char* fmt, ...);
 // raise a kernel's dynamic-LDS limit on the CURRENT device (once per (kernel, device)); 0 or -2 with the error set
 int frmap_big_lds(const void* kern, int bytes);
+// second-generation fused ResNet stem (stem_s2d.hip): 1 = launched, 0 = shape not taken, < 0 = error
+int frmap_stem_s2d(const float* x_nchw, const unsigned char* x_u8, const float* mean3, const float* std3, const void* w_packed_c3,
+                   const float* shift, void* out, int B, int Hi, int Wi, int dtype, hipStream_t st);
 int frmap_batch_invariant();   // 1: planners must not look at the batch size (c_api.cpp)
 // second-generation 3x3 stride-1 kernel (conv_pp.hip): 1 = launched, 0 = shape not taken, < 0 = error
 struct FrmapPPShortcut {  // fused 1x1 projection shortcut: out += W . x[n, oy * stride, ox * stride, :]

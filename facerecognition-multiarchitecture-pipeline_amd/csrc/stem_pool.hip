@@ -332,6 +332,11 @@ static int stem_launch(const float* x_nchw, const unsigned char* x_u8, const flo
     FRMAP_REQUIRE(mean3 && std3 && std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, "%s: mean / non-zero std required", who);
     FRMAP_REQUIRE(Wi % 4 == 0 && ((uintptr_t)x_u8 & 3) == 0, "%s: uint8 input needs W %% 4 == 0 and a 4-byte aligned tensor (W=%d)", who, Wi);
   }
+  if (pool3) {   // the ResNet stem: second-generation kernel (space-to-depth K axis, carried pool row) where it takes the shape
+    const int rc = frmap_stem_s2d(x_nchw, x_u8, p.mean, p.std, w_packed_c3, shift, out, B, Hi, Wi, dtype, (hipStream_t)stream);
+    if (rc < 0) return rc;
+    if (rc == 1) return 0;
+  }
   p.N = B; p.Hi = Hi; p.Wi = Wi;
   p.Hc = (Hi + 6 - 7) / 2 + 1; p.Wc = (Wi + 6 - 7) / 2 + 1;
   if (pool3) { p.Hq = (p.Hc + 2 - 3) / 2 + 1; p.Wq = (p.Wc + 2 - 3) / 2 + 1; }
