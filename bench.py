@@ -21,9 +21,10 @@ the JSON line) and exits non-zero if any rank does.  `FRMAP_BENCH_BACKEND=gloo` 
 flow on a box with fewer GPUs than ranks (ranks share devices; the collective runs over gloo on host copies).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with:
-  roofline      — the dominant kernel (conv3x3_fast_kernel<BF16, false>: the 3×3 stride-1 implicit-GEMM
+  roofline      — the dominant kernel (conv3x3_pp_kernel<BF16>: the 3×3 stride-1 implicit-GEMM
                   convolutions of layers 2-4): algorithmic FLOPs per launch ÷ its average launch duration,
                   measured with HIP events on the launch stream in an instrumented pass after the timed region
+                  ('cnn' / 'arcface': the model handle's own per-launch trace, frmap_model_trace; other families: the per-op wrappers)
                   (standalone eager launches at the full per-GPU batch on one stream: per-kernel durations are not
                   defined for kernels that share the GPU with another stream's, and rocprofv3 serialises the
                   streams).  peak = 2.5 PFLOP/s dense bf16.  `layerwise` lists every kernel of the step with its
@@ -35,6 +36,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with:
   fp16_value    — the same step in fp16 (the precision the north-star's 1e-3 / identical-top-1 tolerance is stated
                   for), timed after the bf16 region in the same process (N = 1 only).
   settle_steps  — untimed steps run BEFORE the W warm-up steps (clock / power-state ramp of a fresh process).
+  step_ms       — median / p10 / p90 / min / max of the per-step durations of the timed region (HIP events between the steps).
+  scale_ref     — (N = 1) the N > 1 workload's per-GPU shape on this one GPU: the like-for-like denominator of a scaling curve.
+  shard_check / local_only — (N > 1) identical inputs gave bit-identical records on every rank (the run aborts otherwise); the same
+                  per-GPU step without the collective.
 """
 from __future__ import annotations
 
@@ -51,7 +56,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/fp16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0       # HBM3E spec, MI355X_MICROARCH.md (≈6.3 TB/s achievable)
-TRAFFIC_PROFILE = "r02_hbm_traffic_pmc.json"
+TRAFFIC_PROFILE = "r03_hbm_traffic_pmc.json"
 
 
 def step_stats(ms):
@@ -217,7 +222,8 @@ def instrument(ops, torch, dt):
     def d_stem(out, x, wpk, shift, dtype, pool3=True):
         B, _, H, W = x.shape
         Hc, Wc = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
-        return f"stem_pool_kernel<{dt}>", 2.0 * B * Hc * Wc * 64 * 147, _nbytes(x) + _nbytes(out) + _nbytes(wpk)
+        name = "stem_s2d_kernel" if (pool3 and W % 4 == 0) else "stem_pool_kernel"
+        return f"{name}<{dt}>", 2.0 * B * Hc * Wc * 64 * 147, _nbytes(x) + _nbytes(out) + _nbytes(wpk)
 
     def d_stem_u8(out, x, wpk, shift, mean, std, dtype, pool3=True):
         B, H, W, _ = x.shape
@@ -305,7 +311,7 @@ def stored_traffic():
     template instantiation (e.g. `conv3x3_pp_kernel<BF16, 7, 2, 3, 1, false, false>`); a bench label such as
     `conv3x3_pp_kernel<BF16>` covers several of them, so the lookup returns, per label, the average HBM bytes per
     LAUNCH over the instantiations it covers, weighted by how often each was launched in the profiled run."""
-    for name in (TRAFFIC_PROFILE, "r01_hbm_traffic_pmc.json"):
+    for name in (TRAFFIC_PROFILE, "r02_hbm_traffic_pmc.json", "r01_hbm_traffic_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 kernels = json.load(f)["kernels"]

@@ -259,7 +259,7 @@ MapOut trunk_features(Run& r, const void* x, int x_kind, int H, int W, char* slo
   const double stem_out = (double)r.B * Hq * Wq * 64 * 2;
   if (x_kind == 1) {
     if (Wq <= 56 && W % 4 == 0) {
-      Traced t(r, "stem_pool_u8_kernel<%s>", stem_flop, (double)r.B * H * W * 3 + stem_out);
+      Traced t(r, ((uintptr_t)x & 3) == 0 ? "stem_s2d_kernel<%s, U8>" : "stem_pool_u8_kernel<%s>", stem_flop, (double)r.B * H * W * 3 + stem_out);
       r.rc = frmap_stem7x7_maxpool_u8((const unsigned char*)x, m->mean, m->stdv, m->stem.wpk, m->stem.shift, buf[0], r.B, H, W, 1, m->dtype, r.st);
     } else {
       r.rc = frmap_normalize_u8_hwc((const unsigned char*)x, nullptr, buf[1], r.B, H, W, m->mean, m->stdv, m->dtype, r.st);
@@ -267,7 +267,8 @@ MapOut trunk_features(Run& r, const void* x, int x_kind, int H, int W, char* slo
       if (!r.rc) r.rc = frmap_maxpool(buf[2], buf[0], r.B, Hc, Wc, 64, 3, 2, 1, m->dtype, r.st);
     }
   } else if (Wq <= 56) {
-    Traced t(r, "stem_pool_kernel<%s>", stem_flop, (double)r.B * H * W * 3 * 4 + stem_out);
+    // (stem_s2d.hip takes 16-byte aligned tensors with W % 4 == 0; stem_pool.hip the rest)
+    Traced t(r, (W % 4 == 0 && ((uintptr_t)x & 15) == 0) ? "stem_s2d_kernel<%s>" : "stem_pool_kernel<%s>", stem_flop, (double)r.B * H * W * 3 * 4 + stem_out);
     r.rc = frmap_stem7x7_maxpool((const float*)x, m->stem.wpk, m->stem.shift, buf[0], r.B, H, W, m->dtype, r.st);
   } else {  // wider than the fused kernel's column strips
     r.rc = frmap_pack_input_nchw_f32((const float*)x, buf[1], r.B, H, W, m->dtype, r.st);

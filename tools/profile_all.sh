@@ -17,5 +17,10 @@ cp "$(find "$out/stats" -name '*kernel_stats.csv' | head -1)" profiles/${tag}_fi
 python3 tools/pmc_traffic.py "$(find "$out/pmcF" -name '*counter_collection.csv' | head -1)" \
   "$(find "$out/pmcW" -name '*counter_collection.csv' | head -1)" profiles/${tag}_hbm_traffic_pmc.json "python3 $cmd" > "$out/traffic.txt"
 python3 tools/sq_summary.py "$(find "$out/pmcS" -name '*counter_collection.csv' | head -1)" profiles/${tag}_final_bench_cnn_bf16_b256_pmc_sq.csv > "$out/sq.txt"
+# kernel stats of the other benchmarked shapes: config 4's per-GPU shape (arcface, 1024 faces, 10 000 IDs) and config 5 (hybrid, 256 faces)
+rocprofv3 --kernel-trace --stats -d "$out/stats4" -o run --output-format csv -- python3 $cmd --model arcface --batch 1024 --gallery 10000 > "$out/stats4.log" 2>&1
+cp "$(find "$out/stats4" -name '*kernel_stats.csv' | head -1)" profiles/${tag}_config4_arcface_b1024_g10000_kernel_stats.csv
+rocprofv3 --kernel-trace --stats -d "$out/stats5" -o run --output-format csv -- python3 $cmd --model hybrid > "$out/stats5.log" 2>&1
+cp "$(find "$out/stats5" -name '*kernel_stats.csv' | head -1)" profiles/${tag}_config5_hybrid_b256_kernel_stats.csv
 mkdir -p gpurun_out/profiles_$tag && cp profiles/${tag}_* gpurun_out/profiles_$tag/
 echo "profiles for $tag regenerated"
