@@ -45,6 +45,7 @@ def bind():
     lib.frmap_match_gallery_pack_bytes.restype = sz
     lib.frmap_match_gallery_pack_bytes.argtypes = [i32, i32]
     lib.frmap_match_pack_gallery.argtypes = [vp, vp, vp, i32, i32, vp]
+    lib.frmap_model_embedding_dim.argtypes = [vp]
     lib.frmap_model_destroy.argtypes = [vp]
     lib.frmap_model_destroy.restype = None
     return lib
@@ -58,7 +59,7 @@ def check(lib, rc, what):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--model", required=True, choices=["cnn", "arcface"])
+    ap.add_argument("--model", required=True, choices=["baseline", "cnn", "siamese", "arcface", "hybrid"])
     ap.add_argument("--dtype", default="f16", choices=["bf16", "f16"])
     ap.add_argument("--classes", type=int, default=36)
     ap.add_argument("--weights", required=True)
@@ -85,11 +86,12 @@ def main():
     x = torch.from_numpy(np.load(a.inputs)["x"]).to(dev)
     B, _, H, W = x.shape
     ws = torch.empty(lib.frmap_model_workspace_bytes(h, B, H, W), dtype=torch.uint8, device=dev)
+    D = lib.frmap_model_embedding_dim(h)                     # 512; SiameseNet: 256
     logits = torch.empty((B, a.classes), dtype=torch.float32, device=dev)
-    emb = torch.empty((B, 512), dtype=torch.float32, device=dev)
+    emb = torch.empty((B, D), dtype=torch.float32, device=dev)
     check(lib, lib.frmap_model_forward(h, x.data_ptr(), IN_F32, B, H, W, OUT_EMB, emb.data_ptr(), ws.data_ptr(), st), "forward(emb)")
     result = {"embedding": None, "tensors_used": np.int64(used)}
-    if a.model == "cnn":                                   # ('arcface' logits need labels-path semantics: val_classifier, see header)
+    if a.model in ("baseline", "cnn", "hybrid"):           # forward() = classifier logits ('arcface': the labels path, see the header; 'siamese': none)
         check(lib, lib.frmap_model_forward(h, x.data_ptr(), IN_F32, B, H, W, OUT_LOGITS, logits.data_ptr(), ws.data_ptr(), st), "forward(logits)")
         result["logits"] = None
     if a.gallery:
@@ -98,9 +100,9 @@ def main():
         G = gal.shape[0]
         packed = stat = None
         if G >= 512:
-            packed = torch.empty(lib.frmap_match_gallery_pack_bytes(G, 512), dtype=torch.uint8, device=dev)
+            packed = torch.empty(lib.frmap_match_gallery_pack_bytes(G, D), dtype=torch.uint8, device=dev)
             stat = torch.empty((G, 4), dtype=torch.float32, device=dev)
-            check(lib, lib.frmap_match_pack_gallery(gal.data_ptr(), packed.data_ptr(), stat.data_ptr(), G, 512, st), "pack_gallery")
+            check(lib, lib.frmap_match_pack_gallery(gal.data_ptr(), packed.data_ptr(), stat.data_ptr(), G, D, st), "pack_gallery")
         ws2 = torch.empty(lib.frmap_model_match_workspace_bytes(h, B, H, W, G), dtype=torch.uint8, device=dev)
         idx = torch.empty(B, dtype=torch.int32, device=dev)
         ids = torch.empty(B, dtype=torch.int32, device=dev)

@@ -7,9 +7,9 @@ OUT=../libfrmap_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result -Wno-unused-value"
 objs=()
 pids=()
-for f in conv_igemm.hip conv_pp.hip conv_small_cin.hip stem_pool.hip stem_s2d.hip layout_pool.hip transformer.hip head_match.hip resize.hip c_api.cpp model_api.cpp; do
+for f in conv_igemm.hip conv_pp.hip conv_small_cin.hip stem_pool.hip stem_s2d.hip layout_pool.hip transformer.hip head_match.hip resize.hip c_api.cpp model_api.cpp model_families.cpp; do
   o="build_${f%.*}.o"
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ frmap_common.h -nt "$o" ] || [ ../../include/frmap_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ frmap_common.h -nt "$o" ] || [ model_api.h -nt "$o" ] || [ ../../include/frmap_hip.h -nt "$o" ]; then
     echo "hipcc $f"
     rm -f "$o"
     if [[ "$f" == *.cpp ]]; then

@@ -11,56 +11,7 @@
 #include <math.h>
 #include <string.h>
 
-#include <map>
-#include <mutex>
-#include <string>
-#include <vector>
-
-#include "frmap_common.h"
-
-namespace {
-
-enum { KIND_CNN = 0, KIND_ARCFACE = 1, KIND_TRUNK = 2 };
-
-struct PackedConv {
-  void* wpk = nullptr;
-  float* shift = nullptr;
-  int cout = 0, cin = 0, k = 0, stride = 1, pad = 0;
-};
-
-struct Block {
-  PackedConv c1, c2, ds;
-  bool has_ds = false;
-  float* fshift = nullptr;  // c2.shift + ds.shift: shift of the fused conv2 + projection-shortcut launch
-};
-
-struct TraceRec {
-  char kernel[64];
-  double flop, bytes;
-  hipEvent_t e0, e1;
-};
-
-}  // namespace
-
-struct frmap_model {
-  int kind = KIND_CNN, dtype = FRMAP_BF16, num_classes = 0, device = 0;
-  bool finalized = false;
-  std::map<std::string, std::vector<float>> raw;  // canonical key -> fp32 host copy (dropped by finalize)
-  PackedConv stem;
-  Block blocks[8];
-  float* fc_w = nullptr;      // cnn: resnet.fc.1 [num_classes][512] / bias
-  float* fc_b = nullptr;
-  float* emb_wt = nullptr;    // arcface: embedding.weight transposed [512][512], folded BatchNorm1d
-  float* bn_scale = nullptr;
-  float* bn_shift = nullptr;
-  float* cls_wn = nullptr;    // arcface: val_classifier.weight with unit rows (face_models.py:576), bias
-  float* cls_b = nullptr;
-  float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};  // src/testing.py:102-103
-  std::vector<void*> allocs;
-  std::mutex trace_mu;
-  bool trace = false;
-  std::vector<TraceRec> recs;
-};
+#include "model_api.h"
 
 namespace {
 
@@ -81,6 +32,7 @@ bool canonical_key(int kind, const std::string& key, std::string* out) {
     *out = std::string("trunk.") + feat_child[idx] + key.substr(dot);
     return true;
   }
+  if (kind >= KIND_BASELINE) return frmap_family_key(kind, key, out);
   if (kind == KIND_CNN) {
     if (starts("resnet.fc.1.")) { *out = "fc." + key.substr(12); return true; }
     if (starts("resnet.fc.")) return false;
@@ -107,6 +59,10 @@ void add_bn(std::map<std::string, size_t>& want, const std::string& p, int c) {
 
 std::map<std::string, size_t> expected_tensors(const frmap_model* m) {
   std::map<std::string, size_t> want;
+  if (m->kind == KIND_BASELINE || m->kind == KIND_SIAMESE) {
+    frmap_family_expected(m, &want);
+    return want;
+  }
   want["trunk.conv1.weight"] = 64 * 3 * 7 * 7;
   add_bn(want, "trunk.bn1", 64);
   int inpl = 64;
@@ -134,25 +90,29 @@ std::map<std::string, size_t> expected_tensors(const frmap_model* m) {
     add_bn(want, "bn", 512);
     want["val_classifier.weight"] = (size_t)m->num_classes * 512;
     want["val_classifier.bias"] = m->num_classes;
+  } else if (m->kind == KIND_HYBRID) {
+    frmap_family_expected(m, &want);
   }
   return want;
 }
 
+}  // namespace
+
 // ---- device memory owned by the handle --------------------------------------------------------------------------------
-void* dev_alloc(frmap_model* m, size_t bytes) {
+void* frmap_model_dev_alloc(frmap_model* m, size_t bytes) {
   void* p = nullptr;
   if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
   m->allocs.push_back(p);
   return p;
 }
-float* dev_upload(frmap_model* m, const std::vector<float>& v) {
-  float* p = (float*)dev_alloc(m, v.size() * sizeof(float));
+float* frmap_model_dev_upload(frmap_model* m, const std::vector<float>& v) {
+  float* p = (float*)frmap_model_dev_alloc(m, v.size() * sizeof(float));
   if (p && hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
   return p;
 }
 
 // eval BatchNorm as y = x * scale + shift (fp32, the Python planner's `_bn_scale_shift`)
-void bn_fold(const frmap_model* m, const std::string& p, int c, std::vector<float>* scale, std::vector<float>* shift) {
+void frmap_model_bn_fold(const frmap_model* m, const std::string& p, int c, std::vector<float>* scale, std::vector<float>* shift) {
   const auto& g = m->raw.at(p + ".weight"); const auto& b = m->raw.at(p + ".bias");
   const auto& mu = m->raw.at(p + ".running_mean"); const auto& var = m->raw.at(p + ".running_var");
   scale->resize(c); shift->resize(c);
@@ -163,20 +123,25 @@ void bn_fold(const frmap_model* m, const std::string& p, int c, std::vector<floa
   }
 }
 
-int pack_conv(frmap_model* m, const std::string& wkey, const std::string& bnkey, int cout, int cin, int k, int stride, int pad,
-              PackedConv* pc, std::vector<float>* shift_host, hipStream_t st) {
-  std::vector<float> scale, shift;
-  bn_fold(m, bnkey, cout, &scale, &shift);
-  std::vector<float> w = m->raw.at(wkey);
+int frmap_model_pack(frmap_model* m, const std::string& wkey, const std::string& bkey, const std::string& bnkey, int cout, int cin,
+                     int k, int stride, int pad, PackedConv* pc, hipStream_t st, const std::vector<float>* w_override) {
+  std::vector<float> scale(cout, 1.f), shift(cout, 0.f);
+  if (!bnkey.empty()) frmap_model_bn_fold(m, bnkey, cout, &scale, &shift);
+  if (!bkey.empty()) {   // a conv / linear bias in front of the BatchNorm lands in the shift: (x + b) * s + t = x * s + (t + b * s)
+    const auto& b = m->raw.at(bkey);
+    for (int o = 0; o < cout; ++o) { volatile float bs = b[o] * scale[o]; shift[o] = shift[o] + bs; }
+  }
+  std::vector<float> w = w_override ? *w_override : m->raw.at(wkey);
   const size_t per = (size_t)cin * k * k;
-  for (int o = 0; o < cout; ++o)
-    for (size_t i = 0; i < per; ++i) w[o * per + i] *= scale[o];
+  if (!bnkey.empty())
+    for (int o = 0; o < cout; ++o)
+      for (size_t i = 0; i < per; ++i) w[o * per + i] *= scale[o];
   float* wdev = nullptr;
   if (hipMalloc((void**)&wdev, w.size() * sizeof(float)) != hipSuccess) { frmap_set_error("model_finalize: out of device memory"); return -2; }
   hipMemcpy(wdev, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice);
   const size_t elems = cin == 3 ? (size_t)cout * frmap_small_cin_kpad(k, k) : w.size();
-  pc->wpk = dev_alloc(m, elems * 2);
-  pc->shift = dev_upload(m, shift);
+  pc->wpk = frmap_model_dev_alloc(m, elems * 2);
+  pc->shift = frmap_model_dev_upload(m, shift);
   pc->cout = cout; pc->cin = cin; pc->k = k; pc->stride = stride; pc->pad = pad;
   int rc = -2;
   if (pc->wpk && pc->shift)
@@ -184,40 +149,41 @@ int pack_conv(frmap_model* m, const std::string& wkey, const std::string& bnkey,
                   : frmap_pack_conv_weight(wdev, pc->wpk, cout, cin, k, k, m->dtype, st);
   hipStreamSynchronize(st);
   hipFree(wdev);
-  if (shift_host) *shift_host = shift;
+  pc->shift_host = shift;
+  return rc;
+}
+
+frmap_traced::frmap_traced(frmap_run& r_, const char* fmt, double flop, double bytes) : r(r_), on(r_.m->trace && !r_.dry) {
+  if (!on) return;
+  snprintf(rec.kernel, sizeof(rec.kernel), fmt, r.dt);
+  rec.flop = flop; rec.bytes = bytes;
+  hipEventCreate(&rec.e0); hipEventCreate(&rec.e1);
+  hipEventRecord(rec.e0, r.st);
+}
+frmap_traced::~frmap_traced() {
+  if (!on) return;
+  hipEventRecord(rec.e1, r.st);
+  std::lock_guard<std::mutex> lock(r.m->trace_mu);
+  r.m->recs.push_back(rec);
+}
+
+namespace {
+
+auto& dev_alloc = frmap_model_dev_alloc;
+auto& dev_upload = frmap_model_dev_upload;
+auto& bn_fold = frmap_model_bn_fold;
+int pack_conv(frmap_model* m, const std::string& wkey, const std::string& bnkey, int cout, int cin, int k, int stride, int pad,
+              PackedConv* pc, std::vector<float>* shift_host, hipStream_t st) {
+  const int rc = frmap_model_pack(m, wkey, "", bnkey, cout, cin, k, stride, pad, pc, st);
+  if (shift_host) *shift_host = pc->shift_host;
   return rc;
 }
 
 // ---- one forward ------------------------------------------------------------------------------------------------------
-struct Run {
-  frmap_model* m;
-  hipStream_t st;
-  int B;
-  const char* dt;
-  int rc = 0;
-};
+using Run = frmap_run;
+using Traced = frmap_traced;
 
 const char* dt_name(int dtype) { return dtype == FRMAP_BF16 ? "BF16" : "F16"; }
-
-// trace support: bracket one launch with events and note its algorithmic work
-struct Traced {
-  Run& r;
-  TraceRec rec;
-  bool on;
-  Traced(Run& r_, const char* fmt, double flop, double bytes) : r(r_), on(r_.m->trace) {
-    if (!on) return;
-    snprintf(rec.kernel, sizeof(rec.kernel), fmt, r.dt);
-    rec.flop = flop; rec.bytes = bytes;
-    hipEventCreate(&rec.e0); hipEventCreate(&rec.e1);
-    hipEventRecord(rec.e0, r.st);
-  }
-  ~Traced() {
-    if (!on) return;
-    hipEventRecord(rec.e1, r.st);
-    std::lock_guard<std::mutex> lock(r.m->trace_mu);
-    r.m->recs.push_back(rec);
-  }
-};
 
 void conv(Run& r, const PackedConv& c, const void* in, int Hi, int Wi, const void* residual, void* out, int relu) {
   if (r.rc) return;
@@ -333,8 +299,11 @@ extern "C" int frmap_model_create(frmap_model** out, const char* model_type, int
   if (!strcmp(model_type, "cnn")) kind = KIND_CNN;
   else if (!strcmp(model_type, "arcface")) kind = KIND_ARCFACE;
   else if (!strcmp(model_type, "resnet18_trunk")) kind = KIND_TRUNK;
-  else { frmap_set_error("Invalid model type: %s (model handles exist for 'cnn', 'arcface', 'resnet18_trunk')", model_type); return -1; }
-  FRMAP_REQUIRE(kind == KIND_TRUNK || num_classes > 0, "model_create: num_classes=%d", num_classes);
+  else if (!strcmp(model_type, "baseline")) kind = KIND_BASELINE;
+  else if (!strcmp(model_type, "siamese")) kind = KIND_SIAMESE;
+  else if (!strcmp(model_type, "hybrid")) kind = KIND_HYBRID;
+  else { frmap_set_error("Invalid model type: %s (model handles exist for 'baseline', 'cnn', 'siamese', 'arcface', 'hybrid', 'resnet18_trunk')", model_type); return -1; }
+  FRMAP_REQUIRE(kind == KIND_TRUNK || kind == KIND_SIAMESE || num_classes > 0, "model_create: num_classes=%d", num_classes);
   frmap_model* m = new (std::nothrow) frmap_model();
   FRMAP_REQUIRE(m, "model_create: out of host memory");
   m->kind = kind; m->dtype = dtype; m->num_classes = num_classes;
@@ -375,9 +344,10 @@ extern "C" int frmap_model_finalize(frmap_model* m, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   for (const auto& kv : expected_tensors(m))
     FRMAP_REQUIRE(m->raw.count(kv.first), "model_finalize: tensor %s was never loaded", kv.first.c_str());
-  int rc = pack_conv(m, "trunk.conv1.weight", "trunk.bn1", 64, 3, 7, 2, 3, &m->stem, nullptr, st);
+  const bool has_trunk = m->kind != KIND_BASELINE && m->kind != KIND_SIAMESE;
+  int rc = has_trunk ? pack_conv(m, "trunk.conv1.weight", "trunk.bn1", 64, 3, 7, 2, 3, &m->stem, nullptr, st) : 0;
   int inpl = 64;
-  for (int li = 0; li < 4 && !rc; ++li) {
+  for (int li = 0; li < 4 && !rc && has_trunk; ++li) {
     const int planes = kStagePlanes[li];
     for (int bi = 0; bi < 2 && !rc; ++bi) {
       Block& b = m->blocks[li * 2 + bi];
@@ -417,6 +387,7 @@ extern "C" int frmap_model_finalize(frmap_model* m, void* stream) {
     if (!m->emb_wt || !m->bn_scale || !m->bn_shift || !cls || !m->cls_wn || !m->cls_b) rc = -2;
     if (!rc) rc = frmap_l2_normalize_f32(cls, m->cls_wn, m->num_classes, 512, 1e-12f, st);   // face_models.py:576
   }
+  if (!rc && m->kind >= KIND_BASELINE) rc = frmap_family_finalize(m, st);
   if (rc == -2 && !*frmap_last_error()) frmap_set_error("model_finalize: out of device memory");
   if (rc) return rc;
   if (hipStreamSynchronize(st) != hipSuccess) { frmap_set_error("model_finalize: stream error"); return -2; }
@@ -425,16 +396,23 @@ extern "C" int frmap_model_finalize(frmap_model* m, void* stream) {
   return 0;
 }
 
-extern "C" int frmap_model_embedding_dim(const frmap_model* m) { return m ? 512 : 0; }
+extern "C" int frmap_model_embedding_dim(const frmap_model* m) { return !m ? 0 : m->kind == KIND_SIAMESE ? 256 : 512; }
 
 extern "C" size_t frmap_model_workspace_bytes(const frmap_model* m, int B, int H, int W) {
   if (!m || B <= 0 || H <= 0 || W <= 0) return 0;
-  return 3 * act_slot_bytes(B, H, W) + 2 * align256((size_t)B * 512 * sizeof(float)) + 256;
+  const size_t heads = 2 * align256((size_t)B * 512 * sizeof(float)) + 256;
+  if (m->kind >= KIND_BASELINE) {   // the families' bump arena, sized by running their forward without launching
+    Run r{const_cast<frmap_model*>(m), nullptr, B, "", 0, true};
+    const size_t fam = frmap_family_forward(r, nullptr, FRMAP_INPUT_F32_NCHW, H, W, FRMAP_OUT_LOGITS, nullptr, nullptr, nullptr, nullptr);
+    if (m->kind == KIND_HYBRID) return 3 * act_slot_bytes(B, H, W) + align256((size_t)B * 49 * 512 * 2) + fam + heads;
+    return fam + heads;
+  }
+  return 3 * act_slot_bytes(B, H, W) + heads;
 }
 
 extern "C" size_t frmap_model_match_workspace_bytes(const frmap_model* m, int B, int H, int W, int G) {
   if (!m || B <= 0) return 0;
-  return frmap_model_workspace_bytes(m, B, H, W) + align256(frmap_match_workspace_bytes(B, G)) + align256((size_t)B * 3 * 512 * 2);
+  return frmap_model_workspace_bytes(m, B, H, W) + align256(frmap_match_workspace_bytes(B, G)) + align256((size_t)B * 3 * 512 * 2);   // (+ the probes' fp16 split)
 }
 
 extern "C" int frmap_model_forward(frmap_model* m, const void* x, int x_kind, int B, int H, int W, int what, void* out,
@@ -446,13 +424,28 @@ extern "C" int frmap_model_forward(frmap_model* m, const void* x, int x_kind, in
   FRMAP_REQUIRE(what >= FRMAP_OUT_TRUNK_MAP && what <= FRMAP_OUT_LOGITS, "model_forward: bad output selector %d", what);
   FRMAP_REQUIRE(m->kind != KIND_TRUNK || what <= FRMAP_OUT_POOLED, "model_forward: a bare trunk has no embedding / logits head");
   Run r{m, (hipStream_t)stream, B, dt_name(m->dtype)};
+  if (m->kind == KIND_BASELINE || m->kind == KIND_SIAMESE) {
+    FRMAP_REQUIRE(what != FRMAP_OUT_POOLED, "model_forward: '%s' has no pooled-trunk output", m->kind == KIND_BASELINE ? "baseline" : "siamese");
+    FRMAP_REQUIRE(m->kind != KIND_SIAMESE || what != FRMAP_OUT_LOGITS, "model_forward: 'siamese' has no classifier head (forward(x1, x2) = two embeddings)");
+    frmap_family_forward(r, x, x_kind, H, W, what, out, nullptr, (char*)workspace, nullptr);
+    return r.rc;
+  }
   const size_t slot = act_slot_bytes(B, H, W);
   char* ws = (char*)workspace;
   float* scratch0 = (float*)(ws + 3 * slot);
+  if (m->kind == KIND_HYBRID && what >= FRMAP_OUT_EMBEDDING) {
+    void* tmap = ws + 3 * slot;
+    const MapOut hm = trunk_features(r, x, x_kind, H, W, ws, slot, tmap);
+    if (r.rc) return r.rc;
+    FRMAP_REQUIRE(hm.h * hm.w == 49, "model_forward: HybridNet expects a 49-token feature map (224x224 input), got %d", hm.h * hm.w);
+    frmap_family_forward(r, nullptr, x_kind, H, W, what, out, nullptr, ws + 3 * slot + align256((size_t)B * 49 * 512 * 2), tmap);
+    return r.rc;
+  }
   const MapOut map = trunk_features(r, x, x_kind, H, W, ws, slot, what == FRMAP_OUT_TRUNK_MAP ? out : nullptr);
   if (r.rc) return r.rc;
   const int HW = map.h * map.w;
   if (what == FRMAP_OUT_TRUNK_MAP) return 0;
+  FRMAP_REQUIRE(m->kind != KIND_HYBRID || what == FRMAP_OUT_POOLED, "model_forward: bad output selector");
   const bool arc = m->kind == KIND_ARCFACE;
   if (what == FRMAP_OUT_POOLED || (!arc && what == FRMAP_OUT_EMBEDDING))
     return frmap_avgpool_global(map.p, (float*)out, B, HW, 512, m->dtype, r.st);
@@ -483,9 +476,36 @@ extern "C" int frmap_model_embed_and_match(frmap_model* m, const void* x, int x_
   Run r{m, (hipStream_t)stream, B, dt_name(m->dtype)};
   const size_t slot = act_slot_bytes(B, H, W);
   char* ws = (char*)workspace;
+  char* match_ws = ws + frmap_model_workspace_bytes(m, B, H, W);
+  if (m->kind >= KIND_BASELINE) {
+    // the family forward fills the embedding the matcher needs: its unit-norm copy when `normalize`, else what get_embedding returns
+    const int D = frmap_model_embedding_dim(m);
+    const size_t model_ws = frmap_model_workspace_bytes(m, B, H, W);
+    float* e0 = (float*)(ws + model_ws - 2 * align256((size_t)B * 512 * sizeof(float)) - 256);
+    float* e1 = e0 + align256((size_t)B * 512 * sizeof(float)) / sizeof(float);
+    float* emb = emb_out ? emb_out : e0;
+    if (m->kind == KIND_HYBRID) {
+      void* tmap = ws + 3 * slot;
+      const MapOut hm = trunk_features(r, x, x_kind, H, W, ws, slot, tmap);
+      if (r.rc) return r.rc;
+      FRMAP_REQUIRE(hm.h * hm.w == 49, "model_embed_and_match: HybridNet expects a 49-token feature map (224x224 input), got %d", hm.h * hm.w);
+      frmap_family_forward(r, nullptr, x_kind, H, W, FRMAP_OUT_EMBEDDING, normalize ? e1 : emb, normalize ? emb : nullptr,
+                           ws + 3 * slot + align256((size_t)B * 49 * 512 * 2), tmap);
+    } else if (m->kind == KIND_BASELINE) {
+      frmap_family_forward(r, x, x_kind, H, W, FRMAP_OUT_EMBEDDING, normalize ? e1 : emb, normalize ? emb : nullptr, ws, nullptr);
+    } else {
+      frmap_family_forward(r, x, x_kind, H, W, FRMAP_OUT_EMBEDDING, emb, nullptr, ws, nullptr);   // (already unit-norm)
+    }
+    if (r.rc) return r.rc;
+    if (gallery_packed && gallery_stat && G >= 512 && D % 32 == 0) {
+      void* split = match_ws + align256(frmap_match_workspace_bytes(B, G));
+      return frmap_match_top1_packed(emb, gallery, gallery_packed, gallery_stat, idx_out, dist_out, id_or_unknown_out, packed_out, thresh,
+                                     match_ws, split, B, G, D, r.st);
+    }
+    return frmap_match_top1(emb, gallery, idx_out, dist_out, id_or_unknown_out, packed_out, thresh, match_ws, B, G, D, r.st);
+  }
   float* scratch0 = (float*)(ws + 3 * slot);
   float* scratch1 = (float*)(ws + 3 * slot + align256((size_t)B * 512 * sizeof(float)));
-  char* match_ws = ws + frmap_model_workspace_bytes(m, B, H, W);
   const MapOut map = trunk_features(r, x, x_kind, H, W, ws, slot, nullptr);
   if (r.rc) return r.rc;
   const int HW = map.h * map.w;

@@ -319,13 +319,21 @@ class BaselineNet(_HipModule):
         self.dropout = nn.Dropout(0.5)
 
     def _build_plan(self, dtype):
+        if not _PY_PLAN and _HEAD_FUSE and _POOL_FUSE:
+            return _TrunkPlan("baseline", dict(self.state_dict()), self.fc2.out_features, dtype, self.input_mean, self.input_std)
         return {"c1": _PackedConv(self.conv1, self.bn1, dtype), "c2": _PackedConv(self.conv2, self.bn2, dtype),
                 "c3": _PackedConv(self.conv3, self.bn3, dtype), "fc1_t": self.fc1.weight.detach().float().t().contiguous()}
+
+    def model_handle(self):
+        p = self._get_plan()
+        return p.handle if isinstance(p, _TrunkPlan) else None
 
     def _embed(self, x):
         """-> (embedding as the reference returns it, its unit-norm copy or None)."""
         x = self._check_input(x)
         p = self._get_plan()
+        if isinstance(p, _TrunkPlan):
+            return p.handle.forward(x, ops.OUT_EMBEDDING), None
         x = self._as_nhwc4(x)
         x = p["c1"].pooled(x)      # self.pool(F.relu(self.bn1(self.conv1(x)))), `face_models.py:38`
         x = p["c2"].pooled(x)
@@ -345,6 +353,9 @@ class BaselineNet(_HipModule):
         return emb if emb is not None else ops.l2_normalize(pre, 1e-12)
 
     def forward(self, x):
+        h = self.model_handle()
+        if h is not None:
+            return h.forward(self._check_input(x), ops.OUT_LOGITS)
         e = self.get_embedding(x)
         return ops.linear_f32(e, self.fc2.weight.detach(), None, self.fc2.bias.detach())
 
@@ -432,6 +443,8 @@ class SiameseNet(_HipModule):
         self.debug_shapes = {}
 
     def _build_plan(self, dtype):
+        if not _PY_PLAN and _POOL_FUSE:
+            return _TrunkPlan("siamese", dict(self.state_dict()), 0, dtype, self.input_mean, self.input_std)
         c = self.conv
         # fc.1 consumes the NCHW flatten (index c*36 + s, `face_models.py:171`); our pooled tensor is
         # NHWC (index s*512 + c): permute the weight's input axis once here.
@@ -445,11 +458,19 @@ class SiameseNet(_HipModule):
             "fc3": _PackedLinearAsConv(self.fc[8].weight, self.fc[8].bias, None, dtype),
         }
 
+    def model_handle(self):
+        p = self._get_plan()
+        return p.handle if isinstance(p, _TrunkPlan) else None
+
     def forward_one(self, x):
         x = self._check_input(x)
         p = self._get_plan()
         batch_size = x.size(0)
         self.debug_shapes["input"] = x.shape
+        if isinstance(p, _TrunkPlan):   # the whole tower is one call on the model handle; the reference's shape log is static
+            self.debug_shapes.update(after_conv=torch.Size((batch_size, 512, 6, 6)), flattened=torch.Size((batch_size, 512 * 6 * 6)),
+                                     before_norm=torch.Size((batch_size, 256)))
+            return p.handle.forward(x, ops.OUT_EMBEDDING)
         convs = p["convs"]
         u8 = x.dtype == torch.uint8
         Wi = x.shape[2] if u8 else x.shape[3]
@@ -668,6 +689,8 @@ class HybridNet(_HipModule):
         self.fc = nn.Linear(self.fdim, num_classes)
 
     def _build_plan(self, dtype):
+        if not _PY_PLAN:
+            return _TrunkPlan("hybrid", dict(self.state_dict()), self.fc.out_features, dtype, self.input_mean, self.input_std)
         tr = self.transformer
         f32 = lambda t: t.detach().float().contiguous()
         return {
@@ -685,6 +708,11 @@ class HybridNet(_HipModule):
         """`face_models.py:705-721`: trunk (no pool) → +pos → pre-LN transformer block → token mean → LN."""
         x = self._check_input(x)
         p = self._get_plan()
+        if isinstance(p, _TrunkPlan):
+            try:
+                return p.handle.forward(x, ops.OUT_EMBEDDING)
+            except ValueError as e:   # (the handle rejects maps that are not 49 tokens with the same message)
+                raise ValueError(str(e).split(": ", 1)[-1]) from None
         f = p["trunk"].features(x)                       # NHWC B×7×7×512 == tokens [B][49][512]
         B, Hh, Ww, D = f.shape
         L = Hh * Ww
@@ -699,7 +727,14 @@ class HybridNet(_HipModule):
         t3 = p["ff2"](hdn, relu=0, residual=t2)                                          # x + ff_out
         return ops.mean_layernorm(t3.view(B, L, D), *p["nf"])
 
+    def model_handle(self):
+        p = self._get_plan()
+        return p.handle if isinstance(p, _TrunkPlan) else None
+
     def forward(self, x):
+        h = self.model_handle()
+        if h is not None:
+            return h.forward(self._check_input(x), ops.OUT_LOGITS)
         e = self.get_embedding(x)
         return ops.linear_f32(e, self.fc.weight.detach(), None, self.fc.bias.detach())
 

@@ -706,6 +706,7 @@ class ModelHandle:
                 _lib.check(lib.frmap_model_set_input_normalization(self._h, m3, s3), "model_set_input_normalization")
             with torch.cuda.device(dev):
                 _lib.check(lib.frmap_model_finalize(self._h, _stream()), "model_finalize")
+            self.embedding_dim = int(lib.frmap_model_embedding_dim(self._h))
         except Exception:
             lib.frmap_model_destroy(self._h)
             self._h = None
@@ -732,7 +733,7 @@ class ModelHandle:
                     hq, wq = (hq - 1) // 2 + 1, (wq - 1) // 2 + 1
                 out = torch.empty((B, hq, wq, 512), dtype=self.dtype, device=x.device)
             else:
-                out = torch.empty((B, self.num_classes if what == OUT_LOGITS else 512), dtype=torch.float32, device=x.device)
+                out = torch.empty((B, self.num_classes if what == OUT_LOGITS else self.embedding_dim), dtype=torch.float32, device=x.device)
             ws = torch.empty((self._lib.frmap_model_workspace_bytes(self._h, B, H, W),), dtype=torch.uint8, device=x.device)
             _lib.check(self._lib.frmap_model_forward(self._h, x.data_ptr(), kind, B, H, W, what, out.data_ptr(), ws.data_ptr(), _stream()),
                        "model_forward")
@@ -748,8 +749,8 @@ class ModelHandle:
             gptr = ppk = pst = 0
             if G:
                 gallery = _dev(gallery, "model_embed_and_match.gallery", torch.float32)
-                if gallery.shape[1] != 512:
-                    raise ValueError(f"embed_and_match: embedding dim 512 != gallery dim {gallery.shape[1]}")
+                if gallery.shape[1] != self.embedding_dim:
+                    raise ValueError(f"embed_and_match: embedding dim {self.embedding_dim} != gallery dim {gallery.shape[1]}")
                 gptr = gallery.data_ptr()
                 if prepared is not None and G >= MATCH_MFMA_MIN_G:
                     if not prepared.matches(gallery):
@@ -760,7 +761,7 @@ class ModelHandle:
             dist = torch.empty((B,), dtype=torch.float32, device=x.device)
             ids = torch.empty((B,), dtype=torch.int32, device=x.device)
             pk = _packed_buf(packed, B, x.device)
-            emb = torch.empty((B, 512), dtype=torch.float32, device=x.device) if want_emb else None
+            emb = torch.empty((B, self.embedding_dim), dtype=torch.float32, device=x.device) if want_emb else None
             ws = torch.empty((self._lib.frmap_model_match_workspace_bytes(self._h, B, H, W, G),), dtype=torch.uint8, device=x.device)
             _lib.check(self._lib.frmap_model_embed_and_match(self._h, x.data_ptr(), kind, B, H, W, gptr, ppk, pst, G, float(thresh),
                                                              int(bool(normalize)), idx.data_ptr(), dist.data_ptr(), ids.data_ptr(),

@@ -361,8 +361,9 @@ int frmap_arcmargin_eval(const float* x, const float* w, const int64_t* label, f
 /* ---------------------------------------------------------------------------------------------
  * Model handles: what `model(images)` / `model.get_embedding(images)` run in the reference
  * (src/testing.py:255-273, src/app.py:44) as ONE call, for the ResNet-18 families of get_model()
- * (src/face_models.py:785-813): 'cnn' = ResNetTransfer (:62-102), 'arcface' = ArcFaceNet eval (:447-613),
- * 'resnet18_trunk' = the bare trunk (features only; HybridNet / AttentionNet build on it, :269,658).
+ * (src/face_models.py:785-813): 'baseline' = BaselineNet (:16-60), 'cnn' = ResNetTransfer (:62-102), 'siamese' = SiameseNet
+ * (one tower of forward(x1, x2), :104-192; 256-d embeddings), 'arcface' = ArcFaceNet eval (:447-613), 'hybrid' = HybridNet
+ * (:650-721), 'resnet18_trunk' = the bare trunk (features only; AttentionNet builds on it, :269).
  *
  *   frmap_model_create       model_type as get_model() spells it; num_classes sizes the classifier head; `dtype` = compute type.
  *                            An unknown type is rejected with the reference's message ("Invalid model type: ...", :813).
@@ -379,10 +380,14 @@ int frmap_arcmargin_eval(const float* x, const float* w, const int64_t* label, f
  *                            `what` selects the output written to the caller-owned `out`:
  *                              FRMAP_OUT_TRUNK_MAP  [B][h][w][512] in `dtype`  (children()[:-2], face_models.py:660)
  *                              FRMAP_OUT_POOLED     fp32 [B][512]              (children()[:-1] flattened, :100,464)
- *                              FRMAP_OUT_EMBEDDING  fp32 [B][512]: get_embedding() - 'cnn': the pooled features (:98-102);
- *                                                   'arcface': F.normalize(bn(embedding(pooled))) (:584-590)
+ *                              FRMAP_OUT_EMBEDDING  fp32 [B][frmap_model_embedding_dim]: get_embedding() - 'cnn': the pooled features
+ *                                                   (:98-102); 'arcface': F.normalize(bn(embedding(pooled))) (:584-590); 'baseline':
+ *                                                   relu(fc1(pooled)) (:51-60); 'siamese': the tower's unit-norm output (:161-179);
+ *                                                   'hybrid': LayerNorm(token mean) (:705-721)
  *                              FRMAP_OUT_LOGITS     fp32 [B][num_classes]: forward() - 'cnn': resnet.fc (:93-96); 'arcface':
- *                                                   val_classifier over row-normalised weights (:576-580)
+ *                                                   val_classifier over row-normalised weights (:576-580); 'baseline': fc2;
+ *                                                   'hybrid': fc; 'siamese': none (rejected)
+ *                            (TRUNK_MAP / POOLED are the ResNet trunk's outputs: 'cnn', 'arcface', 'hybrid', 'resnet18_trunk'.)
  *                            workspace: frmap_model_workspace_bytes(m, B, H, W) bytes, 256-byte aligned, caller-owned.
  *                            Nothing is allocated, freed or synchronised; all launches go to `stream`.
  *   frmap_model_embed_and_match  forward + compare_faces for every face (src/app.py:44,50-64): embedding (L2-normalised first if
