@@ -575,6 +575,10 @@ def worker(args) -> int:
         # 'cnn' / 'arcface' run on a model handle of the C ABI: its per-launch trace (HIP events recorded by the library around
         # every launch of the forward) supplies the records; the other families are timed through the per-op wrappers
         handle = model.model_handle() if hasattr(model, "model_handle") else None
+        if handle is None:   # AttentionNet: its ResNet-18 trunk runs on a 'resnet18_trunk' handle, the attention head through per-op calls
+            plan = model._get_plan() if hasattr(model, "_get_plan") else None
+            trunk = plan.get("trunk") if isinstance(plan, dict) else None
+            handle = getattr(trunk, "handle", None)
         NREP = 5
         try:
             if handle is not None:
