@@ -434,10 +434,15 @@ extern "C" int frmap_model_forward(frmap_model* m, const void* x, int x_kind, in
   char* ws = (char*)workspace;
   float* scratch0 = (float*)(ws + 3 * slot);
   if (m->kind == KIND_HYBRID && what >= FRMAP_OUT_EMBEDDING) {
+    {   // (checked BEFORE anything is launched: a rejected call launches nothing)
+      int th = ((H + 6 - 7) / 2 + 1 + 2 - 3) / 2 + 1, tw = ((W + 6 - 7) / 2 + 1 + 2 - 3) / 2 + 1;
+      for (int i = 0; i < 3; ++i) { th = (th - 1) / 2 + 1; tw = (tw - 1) / 2 + 1; }
+      FRMAP_REQUIRE(th * tw == 49, "model_forward: HybridNet expects a 49-token feature map (224x224 input), got %d", th * tw);
+    }
     void* tmap = ws + 3 * slot;
     const MapOut hm = trunk_features(r, x, x_kind, H, W, ws, slot, tmap);
     if (r.rc) return r.rc;
-    FRMAP_REQUIRE(hm.h * hm.w == 49, "model_forward: HybridNet expects a 49-token feature map (224x224 input), got %d", hm.h * hm.w);
+    (void)hm;
     frmap_family_forward(r, nullptr, x_kind, H, W, what, out, nullptr, ws + 3 * slot + align256((size_t)B * 49 * 512 * 2), tmap);
     return r.rc;
   }
@@ -485,10 +490,12 @@ extern "C" int frmap_model_embed_and_match(frmap_model* m, const void* x, int x_
     float* e1 = e0 + align256((size_t)B * 512 * sizeof(float)) / sizeof(float);
     float* emb = emb_out ? emb_out : e0;
     if (m->kind == KIND_HYBRID) {
+      int th = ((H + 6 - 7) / 2 + 1 + 2 - 3) / 2 + 1, tw = ((W + 6 - 7) / 2 + 1 + 2 - 3) / 2 + 1;
+      for (int i = 0; i < 3; ++i) { th = (th - 1) / 2 + 1; tw = (tw - 1) / 2 + 1; }
+      FRMAP_REQUIRE(th * tw == 49, "model_embed_and_match: HybridNet expects a 49-token feature map (224x224 input), got %d", th * tw);
       void* tmap = ws + 3 * slot;
-      const MapOut hm = trunk_features(r, x, x_kind, H, W, ws, slot, tmap);
+      trunk_features(r, x, x_kind, H, W, ws, slot, tmap);
       if (r.rc) return r.rc;
-      FRMAP_REQUIRE(hm.h * hm.w == 49, "model_embed_and_match: HybridNet expects a 49-token feature map (224x224 input), got %d", hm.h * hm.w);
       frmap_family_forward(r, nullptr, x_kind, H, W, FRMAP_OUT_EMBEDDING, normalize ? e1 : emb, normalize ? emb : nullptr,
                            ws + 3 * slot + align256((size_t)B * 49 * 512 * 2), tmap);
     } else if (m->kind == KIND_BASELINE) {

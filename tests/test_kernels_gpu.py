@@ -124,6 +124,33 @@ def test_fused_stem_maxpool(dtype, B, H, W):
     assert torch.allclose(y, ref, atol=atol, rtol=rtol), (y - ref).abs().max()
 
 
+@pytest.mark.parametrize("B,H,W", [(1, 224, 224), (2, 61, 36), (1, 226, 220), (2, 34, 200), (300, 64, 64), (7, 160, 160), (3, 35, 8)])
+def test_stem_s2d_segments_borders_and_many_units(B, H, W):
+    """`stem_s2d_kernel` (W % 4 == 0) on the shapes its structure branches on: one image cut into 19 row segments (every
+    segment but the first computes its carry row alone), odd conv heights / widths (the row / column past the last conv
+    position acts as -inf: masking path), a single column half, several units per persistent workgroup, tiny maps; fp32 and the
+    uint8 twin; against fp32 torch on the same rounded operands."""
+    dtype = torch.float16
+    x = synth.randn(125, (B, 3, H, W), "x")
+    w = (synth.randn(126, (64, 3, 7, 7), "w") * math.sqrt(2.0 / 147)).to(dtype)
+    shift = synth.randn(127, (64,), "b") * 0.3
+    conv = F.relu(F.conv2d(x.to(dtype).float(), w.float(), None, stride=2, padding=3) + shift.view(1, -1, 1, 1))
+    ref = F.max_pool2d(conv.to(dtype).float(), 3, 2, 1)
+    wpk = ops.pack_conv_weight_c3(w.float().to(DEV), dtype)
+    y = ops.stem7x7_maxpool(x.to(DEV), wpk, shift.to(DEV), dtype).float().cpu().permute(0, 3, 1, 2)
+    atol, rtol = _tol(dtype)
+    assert y.shape == ref.shape
+    assert torch.allclose(y, ref, atol=atol, rtol=rtol), (y - ref).abs().max()
+    if B <= 8:   # uint8 twin: bit-identical to normalise -> fp32 entry
+        g = np.random.Generator(np.random.PCG64(128))
+        x8 = torch.from_numpy(g.integers(0, 256, (B, H, W, 3), dtype=np.uint8)).to(DEV)
+        mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+        xf = ops.normalize_u8(x8, mean, std)[0]
+        a = ops.stem7x7_maxpool_u8(x8, wpk, shift.to(DEV), mean, std, dtype)
+        b = ops.stem7x7_maxpool(xf.to(dtype).float(), wpk, shift.to(DEV), dtype)
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,W", [(3, 224, 224), (2, 100, 84), (2, 61, 37)])
 def test_fused_stem_maxpool2x2(dtype, B, H, W):
