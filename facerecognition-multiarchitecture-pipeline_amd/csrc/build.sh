@@ -62,3 +62,10 @@ if [ "$fail" != 0 ]; then
 fi
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "${objs[@]}"
 echo "built $(realpath $OUT)"
+# the plain-C host of the model-level ABI (examples/cabi_host.c): gcc + the HIP runtime, no Python
+EX=../../examples
+if [ ! -f $EX/cabi_host ] || [ $EX/cabi_host.c -nt $EX/cabi_host ] || [ ../../include/frmap_hip.h -nt $EX/cabi_host ]; then
+  gcc $EX/cabi_host.c -I../../include -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -O2 -o $EX/cabi_host -L.. -l:libfrmap_hip.so \
+      -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$ORIGIN/../facerecognition-multiarchitecture-pipeline_amd' -Wl,-rpath,/opt/rocm/lib
+  echo "built $(realpath $EX/cabi_host)"
+fi

@@ -128,6 +128,50 @@ def test_ctypes_only_host_arcface_large_gallery(tmp_path, calibrated_sd):
     assert float(np.abs(out["dist"] - want_d.numpy()).max()) < 6e-3
 
 
+def _write_weights_bin(path, sd):
+    import struct
+    items = [(k, v.numpy().astype(np.float32).ravel()) for k, v in sd.items() if v.dtype.is_floating_point]
+    with open(path, "wb") as f:
+        f.write(struct.pack("<i", len(items)))
+        for k, a in items:
+            kb = k.encode()
+            f.write(struct.pack("<i", len(kb))); f.write(kb); f.write(struct.pack("<q", a.size)); f.write(a.tobytes())
+
+
+@pytest.mark.parametrize("mt,G", [("cnn", 36), ("arcface", 10000)])
+def test_plain_c_host_runs_model_and_match(mt, G, tmp_path, gold_dir, calibrated_sd):
+    """`examples/cabi_host.c` - a C program (gcc, HIP runtime for device memory, libfrmap_hip.so; no Python anywhere in the
+    process) - loads the checkpoint under the reference's keys, embeds the golden inputs and matches them against a gallery
+    that holds their oracle embeddings: embeddings vs the reference-generated golden, top-1 = own row."""
+    import struct
+    host = os.path.join(ROOT, "examples", "cabi_host")
+    assert os.path.isfile(host), "examples/cabi_host is built by csrc/build.sh (__graft_entry__.build())"
+    z = np.load(os.path.join(gold_dir, f"{mt}.npz"))
+    sd = calibrated_sd(mt)
+    x = weights.golden_inputs(mt)
+    _write_weights_bin(tmp_path / "w.bin", sd)
+    with open(tmp_path / "x.bin", "wb") as f:
+        f.write(struct.pack("<iii", x.shape[0], x.shape[2], x.shape[3])); f.write(x.numpy().astype(np.float32).tobytes())
+    gold = torch.from_numpy(z["embedding"])
+    gal = synth.unit_rows(3004, G, 512)
+    rows = [(G // 16) * i + 1 for i in range(16)]
+    gal[rows] = F.normalize(gold, dim=1)                                       # enrol the reference's own embeddings
+    with open(tmp_path / "g.bin", "wb") as f:
+        f.write(struct.pack("<iifi", G, 512, 1.0, 1 if mt == "cnn" else 0)); f.write(gal.numpy().astype(np.float32).tobytes())
+    r = subprocess.run([host, mt, "36", "f16", str(tmp_path / "w.bin"), str(tmp_path / "x.bin"), str(tmp_path / "g.bin"),
+                        str(tmp_path / "o.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    raw = open(tmp_path / "o.bin", "rb").read()
+    B, D = struct.unpack("<ii", raw[:8])
+    emb = torch.from_numpy(np.frombuffer(raw, np.float32, B * D, 8).reshape(B, D).copy())
+    ids = np.frombuffer(raw, np.int32, B, 8 + 4 * B * D)
+    dist = np.frombuffer(raw, np.float32, B, 8 + 4 * B * D + 4 * B)
+    assert (B, D) == (16, 512)
+    assert float((emb - gold).norm() / gold.norm()) < 8e-3
+    assert ids.tolist() == rows and float(dist.max()) < 5e-2                   # every face finds its own enrolment
+    print(r.stdout.strip())
+
+
 def test_model_handle_rejections():
     import ctypes as C
     from frmap_amd import _lib
