@@ -714,8 +714,11 @@ class ModelHandle:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
-            self._lib.frmap_model_destroy(h)
+        try:
+            if h:
+                self._lib.frmap_model_destroy(h)
+        except Exception:   # interpreter shutdown: the library object may already be gone
+            pass
 
     @staticmethod
     def _geometry(x):
