@@ -157,3 +157,22 @@ def test_product_package_never_imports_the_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "import oracle" not in src and "from oracle" not in src, fn
+
+
+def test_predict_image_discovery_errors_match_the_reference(tmp_path):
+    """`src/testing.py:532-558`: the checks that run before any model is built raise the reference's messages (no GPU needed)."""
+    from frmap_amd import evaluate
+    ck, proc = tmp_path / "checkpoints", tmp_path / "processed"
+    ck.mkdir()
+    with pytest.raises(ValueError, match="No trained models found for type: cnn"):
+        evaluate.predict_image("cnn", "x.png", checkpoints_dir=str(ck), proc_data_dir=str(proc))
+    with pytest.raises(ValueError, match="Model not found: cnn_v3"):
+        evaluate.predict_image("cnn", "x.png", model_name="cnn_v3", checkpoints_dir=str(ck), proc_data_dir=str(proc))
+    (ck / "cnn_v1").mkdir(); (ck / "cnn_v2").mkdir(); (ck / "siamese_v1").mkdir()
+    with pytest.raises(ValueError, match="No processed datasets found."):
+        evaluate.predict_image("cnn", "x.png", checkpoints_dir=str(ck), proc_data_dir=str(proc))
+    (proc / "lfw" / "train" / "alice").mkdir(parents=True)
+    with pytest.raises(ValueError, match="Siamese model can't be used for direct prediction"):
+        evaluate.predict_image("siamese", "x.png", checkpoints_dir=str(ck), proc_data_dir=str(proc))
+    with pytest.raises(FileNotFoundError):                       # the image itself (the latest directory, cnn_v2, was picked)
+        evaluate.predict_image("cnn", str(tmp_path / "missing.png"), checkpoints_dir=str(ck), proc_data_dir=str(proc))
