@@ -291,3 +291,76 @@ def predict_image(model_type: str, image_path: str, model_name: Optional[str] = 
         probs, pred = ops.softmax_argmax(outputs)
         pred_idx = int(pred[0])
         return classes[pred_idx], float(probs[0, pred_idx])
+
+
+# ------------------------------------------------------------------------------------------------
+# `src/testing.py:26-131`: the discovery half of the reference's evaluate_model (which checkpoint, which processed dataset)
+# ------------------------------------------------------------------------------------------------
+def find_processed_datasets(proc_data_dir: str):
+    """`testing.py:43-70`: ``[(path, display name)]`` of the processed datasets that hold a ``test`` split - ``<config>/test``,
+    ``<config>/<dataset>/test`` and the root's own ``test``, in the reference's order, de-duplicated by display name."""
+    from pathlib import Path
+    root = Path(proc_data_dir)
+    found, names = [], set()
+    if not root.exists():
+        return found
+    for config_dir in [d for d in root.iterdir() if d.is_dir() and d.name not in ["train", "val", "test"]]:
+        if (config_dir / "test").exists():
+            if config_dir.name not in names:
+                found.append((config_dir, config_dir.name)); names.add(config_dir.name)
+        else:
+            for dataset_dir in config_dir.iterdir():
+                if dataset_dir.is_dir() and (dataset_dir / "test").exists():
+                    disp = f"{config_dir.name}/{dataset_dir.name}"
+                    if disp not in names:
+                        found.append((dataset_dir, disp)); names.add(disp)
+    if (root / "test").exists() and "root" not in names:
+        found.append((root, "processed (root)"))
+    return found
+
+
+def evaluate_trained(model_type: str, model_name: Optional[str] = None, auto_dataset: bool = True, dataset_index: int = 0,
+                     checkpoints_dir: str = "outputs/checkpoints", proc_data_dir: str = "data/processed",
+                     out_root: Optional[str] = "outputs", device="cuda") -> dict:
+    """The reference's ``evaluate_model(model_type, model_name=None, auto_dataset=False)`` (`src/testing.py:26-394`) end to end on
+    the HIP path: the latest ``<model_type>_*`` directory under ``checkpoints_dir`` unless ``model_name`` is given
+    (``ValueError("No trained models found for type: …")`` / ``ValueError("Model not found: …")``, `:31-40`), the processed datasets
+    that hold a ``test`` split (``ValueError("No processed datasets found with test data.")``, `:67`), ``best_model.pth`` before
+    ``best_checkpoint.pth`` (``FileNotFoundError``, `:129`), then the loop + metrics + JSON of `evaluate_model` with results under
+    ``<out_root>/<model_name>`` (`:94-96`).  The interactive dataset prompt (`:74-90`) becomes ``dataset_index`` (``auto_dataset``
+    picks the first, as the reference's flag does).  Siamese pair datasets (`data_utils.SiameseDataset`) are outside the scope:
+    pass pair batches to `evaluate_model` directly."""
+    import os
+    from pathlib import Path
+    from .face_models import get_model
+    ckpt_root = Path(checkpoints_dir)
+    if model_name is None:
+        model_dirs = list(ckpt_root.glob(f'{model_type}_*'))
+        if not model_dirs:
+            raise ValueError(f"No trained models found for type: {model_type}")
+        model_name = sorted(model_dirs)[-1].name
+    model_checkpoint_dir = ckpt_root / model_name
+    if not model_checkpoint_dir.exists():
+        raise ValueError(f"Model not found: {model_name}")
+    processed_dirs = find_processed_datasets(proc_data_dir)
+    if not processed_dirs:
+        raise ValueError("No processed datasets found with test data.")
+    if model_type == 'siamese':
+        raise ValueError("siamese evaluation takes an iterable of (img1, img2, labels) batches: use evaluate_model")
+    idx = 0 if auto_dataset else int(dataset_index)
+    if not 0 <= idx < len(processed_dirs):
+        raise ValueError(f"dataset_index {dataset_index} out of range (1..{len(processed_dirs)} datasets)")
+    selected_data_dir, display = processed_dirs[idx]
+    test_dir = selected_data_dir / "test"
+    classes = sorted(d.name for d in os.scandir(test_dir) if d.is_dir())
+    model = get_model(model_type, len(classes)).to(device)
+    best_model_path, best_checkpoint_path = model_checkpoint_dir / 'best_model.pth', model_checkpoint_dir / 'best_checkpoint.pth'
+    if best_model_path.exists():
+        model.load_state_dict(torch.load(best_model_path, map_location=device, weights_only=True))
+    elif best_checkpoint_path.exists():
+        model.load_state_dict(torch.load(best_checkpoint_path, map_location=device, weights_only=True))
+    else:
+        raise FileNotFoundError(f"Neither best_model.pth nor best_checkpoint.pth found in {model_checkpoint_dir}")
+    model.eval()
+    out_dir = str(Path(out_root) / model_name) if out_root is not None else None
+    return evaluate_model(model, model_type, str(test_dir), out_dir=out_dir, model_name=model_name, dataset_name=display, device=device)

@@ -567,3 +567,30 @@ def test_predict_image_mirror(tmp_path, calibrated_sd):
         evaluate.predict_image("siamese", str(img), checkpoints_dir=str(ck), proc_data_dir=str(proc))
     with pytest.raises(ValueError, match="No processed datasets found"):
         evaluate.predict_image("cnn", str(img), checkpoints_dir=str(ck), proc_data_dir=str(tmp_path / "nowhere"))
+
+
+def test_evaluate_trained_end_to_end(tmp_path, calibrated_sd):
+    """`src/testing.py:26-394` as one call: latest checkpoint directory + first processed dataset with a test split -> the same
+    results as handing the loaded model and the folder to `evaluate_model`, and the reference's JSON files under <out>/<model_name>."""
+    import json
+    from PIL import Image
+    from frmap_amd import evaluate
+    g = np.random.Generator(np.random.PCG64(123))
+    proc, ck, out = tmp_path / "processed", tmp_path / "checkpoints", tmp_path / "outputs"
+    test_dir = proc / "cfg" / "lfw" / "test"
+    for c in range(36):
+        d = test_dir / f"person_{c:02d}"
+        d.mkdir(parents=True)
+        if c < 6:
+            for i in range(2):
+                Image.fromarray(g.integers(0, 256, (150 + 9 * c, 130 + 7 * i, 3), dtype=np.uint8)).save(d / f"img_{i}.png")
+    (ck / "baseline_v1").mkdir(parents=True); (ck / "baseline_v2").mkdir()
+    torch.save(calibrated_sd("baseline"), ck / "baseline_v2" / "best_checkpoint.pth")      # (`:121-127`: the fallback file name)
+    res = evaluate.evaluate_trained("baseline", checkpoints_dir=str(ck), proc_data_dir=str(proc), out_root=str(out))
+    m = _model("baseline", calibrated_sd("baseline"), torch.bfloat16)
+    ref = evaluate.evaluate_model(m, "baseline", str(test_dir))
+    assert res["predictions"] == ref["predictions"] and res["targets"] == ref["targets"] and len(res["targets"]) == 12
+    assert np.allclose(np.array(res["probabilities"]), np.array(ref["probabilities"]), atol=1e-6)
+    summary = json.load(open(out / "baseline_v2" / "experiment_summary.json"))
+    assert summary["model_name"] == "baseline_v2" and summary["dataset"] == "cfg/lfw"
+    assert (out / "baseline_v2" / "baseline_model_results.json").exists()

@@ -176,3 +176,25 @@ def test_predict_image_discovery_errors_match_the_reference(tmp_path):
         evaluate.predict_image("siamese", "x.png", checkpoints_dir=str(ck), proc_data_dir=str(proc))
     with pytest.raises(FileNotFoundError):                       # the image itself (the latest directory, cnn_v2, was picked)
         evaluate.predict_image("cnn", str(tmp_path / "missing.png"), checkpoints_dir=str(ck), proc_data_dir=str(proc))
+
+
+def test_evaluate_trained_discovery_matches_the_reference(tmp_path):
+    """`src/testing.py:31-70,129`: dataset discovery order / names and the errors raised before any model runs (no GPU needed)."""
+    from frmap_amd import evaluate
+    proc = tmp_path / "processed"
+    for d in ("cfgA/test/x", "cfgB/lfw/test/x", "cfgB/celeb/test/x", "cfgB/notes", "test/x", "train/x"):
+        (proc / d).mkdir(parents=True)
+    found = evaluate.find_processed_datasets(str(proc))
+    assert sorted(n for _, n in found) == sorted(["cfgA", "cfgB/lfw", "cfgB/celeb", "processed (root)"])
+    assert found[-1][1] == "processed (root)"                                   # the root's own split comes last (`:62-65`)
+    ck = tmp_path / "checkpoints"
+    ck.mkdir()
+    with pytest.raises(ValueError, match="No trained models found for type: baseline"):
+        evaluate.evaluate_trained("baseline", checkpoints_dir=str(ck), proc_data_dir=str(proc))
+    (ck / "baseline_v1").mkdir()
+    with pytest.raises(ValueError, match="Model not found: baseline_v7"):
+        evaluate.evaluate_trained("baseline", "baseline_v7", checkpoints_dir=str(ck), proc_data_dir=str(proc))
+    with pytest.raises(ValueError, match="No processed datasets found with test data."):
+        evaluate.evaluate_trained("baseline", checkpoints_dir=str(ck), proc_data_dir=str(tmp_path / "empty"))
+    with pytest.raises(ValueError, match="dataset_index"):
+        evaluate.evaluate_trained("baseline", auto_dataset=False, dataset_index=9, checkpoints_dir=str(ck), proc_data_dir=str(proc))
