@@ -184,7 +184,9 @@ def get_embedding(face_img, model):
 
 
 def compare_faces(emb, refs, thresh):
-    """`app.py:50-64` on the GPU."""
+    """`app.py:50-64` on the GPU.  ``refs``: the reference's list of dicts (its device copy is cached and re-validated against the
+    live list on every call - an O(len(refs)) walk over version counters, ~1 us per entry: fine for the demo's tens of entries) or
+    a `Gallery` (no walk: what a host with thousands of identities should hold; `Gallery.append` enrols in O(1))."""
     if emb is None or refs is None or len(refs) == 0:
         return "Unknown", float('inf'), None
     dev = emb.device if emb.is_cuda else torch.device("cuda")
